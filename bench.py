@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Direct N^2 + Velocity Verlet at N = 1,048,576 (Plummer sphere,
+eps = 1e-3, fp32) on 1/2/4/8 MI355X.  One "step" = one full Velocity-Verlet step (drift, all-pairs
+forces, kick).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+value   = pair interactions per second of the whole job = N^2 * K / t  (self pairs counted,
+          they contribute exactly 0), inputs resident in HBM
+scaling = "strong": the total body count stays 1,048,576 as the GPU count grows (BASELINE.json
+          config 3); each rank owns N/P targets and all-gathers 16 B/body once per step.
+roofline: the dominant kernel is nbh::direct_kernel.  It is FP32-VALU issue bound (no MFMA: the
+          pair interaction is not a contraction; HBM traffic is 32 B/body per launch), so `bound`
+          is "valu" with the FP32 vector peak of MICROARCH.md (157.3 TFLOP/s) and 20 flop per
+          pair interaction; the HBM view is given beside it.
+cpu_baseline: the oracle's restatement of the reference loop (fp32, sequential accumulation,
+          OpenMP over targets) on a bounded sample of the same workload, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 20.0          # Nyland/Harris/Prins convention, SURVEY.md section 8d
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (vector)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20, help="total bodies (default 1,048,576)")
+    ap.add_argument("--eps", type=float, default=1e-3)
+    ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant override (experiments)")
+    ap.add_argument("--tpl", type=int, default=0, help="targets per lane override")
+    ap.add_argument("--splits", type=int, default=0, help="source splits override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
+    ap.add_argument("--kernel-iters", type=int, default=3, help="launches for the roofline timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(ic, eps, seconds):
+    """Times the oracle (kind "port": the reference has no CPU force path) on a
+    bounded sample: T targets spread over the index range x all N sources, fp32 sequential sum."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind
+    lib = None
+    # rebuild the timing build for THIS host's cores when a compiler is around
+    try:
+        tmp = tempfile.mkdtemp(prefix="nbody_oracle_")
+        so = os.path.join(tmp, "libnbody_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-ffp-contract=off",
+                               "-fno-fast-math", "-fvisibility=hidden", "-shared", "-o", so,
+                               os.path.join(ROOT, "oracle", "nbody_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = oracle_bind.Oracle(so)
+    except Exception:
+        lib = oracle_bind.load(fast=True)
+    n = ic["pos_x"].size
+    eps2 = float(np.float32(eps) * np.float32(eps))
+    cores = lib.num_threads()
+    x, y, z, m = ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"]
+
+    def run(t):
+        idx = np.linspace(0, n - 1, t).astype(np.int64)
+        t0 = time.perf_counter()
+        lib.direct_forces_indexed(x, y, z, m, idx, 1.0, eps2, 0)
+        return time.perf_counter() - t0
+
+    t_probe = max(cores * 4, 32)
+    dt = run(t_probe)
+    rate = t_probe * n / dt
+    targets = int(min(n, max(t_probe, rate * seconds / n)))
+    targets = max(cores, targets // cores * cores)
+    dt = run(targets)
+    return {"value": targets * n / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
+            "sample": f"{targets} of {n} targets x all {n} sources, fp32 sequential sum "
+                      f"(oracle mode 0), OpenMP over targets, {dt:.1f} s"}
+
+
+def read_pmc_traffic():
+    """HBM bytes per direct_kernel launch from the committed rocprofv3 PMC summary, if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("direct_kernel", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import nbody_amd as nb
+    from nbody_amd.distributed import HipBackend, ShardedDirectSystem
+
+    ctx = nb.default_context(local_rank)
+    if a.variant >= 0 or a.tpl or a.splits:
+        ctx.tuning(max(a.variant, 0), a.tpl, a.splits)
+
+    n = a.n
+    ic = nb.ic.plummer(n, seed=42)  # every rank builds the same bodies, keeps its shard
+    G, eps, dt = 1.0, a.eps, a.dt
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        # the drop-in path: 13-array ParticleData behind ForceCalculator / Integrator
+        d = nb.ParticleData()
+        nb.ParticleDataManager.allocateDevice(d, n)
+        h = nb.ParticleData()
+        nb.ParticleDataManager.allocateHost(h, n)
+        for k, v in ic.items():
+            getattr(h, k)[:] = v
+        nb.ParticleDataManager.copyToDevice(d, h)
+        fc = nb.DirectForceCalculator()
+        fc.setGravitationalConstant(G)
+        fc.setSofteningParameter(eps)
+        integ = nb.Integrator()
+        fc.computeForces(d)  # a(0), ParticleSystem::initialize (particle_system.cpp:88-91)
+        step = lambda: integ.integrate(d, fc, dt)  # noqa: E731
+        path = "ParticleSystem-style: Integrator.integrate(ParticleData, DirectForceCalculator)"
+    else:
+        sysm = ShardedDirectSystem(ic, G, eps, backend=HipBackend(ctx))
+        sysm.initial_forces()
+        step = lambda: sysm.step(dt)  # noqa: E731
+        path = "index-range shards, RCCL all-gather of float4 positions per step"
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        pairs = float(n) * float(n) * a.steps
+        value = pairs / elapsed
+        out = {
+            "metric": "pair_interactions_per_s", "value": value, "unit": "pair-interactions/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "steps_per_s": a.steps / elapsed,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"plummer_N{n}_direct_n2_velocity_verlet", "bodies": n,
+                       "eps": eps, "dt": dt, "G": G, "seed": 42, "path": path,
+                       "sharding": f"targets_by_index_range_x{world}"},
+        }
+        # --- roofline of the dominant kernel, timed live with HIP events on the launch stream
+        nt = n // world
+        p = torch.from_numpy(np.ascontiguousarray(
+            np.stack([ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"]], 1))).cuda()
+        eps2 = float(np.float32(eps) * np.float32(eps))
+        ms = nb.time_direct_packed(ctx, p[:nt].contiguous(), p, G, eps2, a.kernel_iters)
+        flops = FLOP_PER_PAIR * nt * n
+        achieved = flops / (ms * 1e-3) / 1e12
+        alg_bytes = 16.0 * n + 16.0 * nt
+        out["roofline"] = {
+            "kernel": "nbh::direct_kernel", "bound": "valu", "achieved": achieved,
+            "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+            "traffic": read_pmc_traffic(),
+            "launch_ms": ms, "pairs_per_launch": float(nt) * n, "flop_per_pair": FLOP_PER_PAIR,
+            "pair_interactions_per_s_kernel": nt * n / (ms * 1e-3),
+            "hbm": {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / (ms * 1e-3) / 1e9,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "note": "FP32 VALU-issue bound (12 VALU + 1 v_rsq per pair), not HBM, no MFMA; "
+                    "launch_ms = HIP-event mean over direct_kernel + its finalize epilogue",
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ic, eps, a.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+/*
+ * nbody_hip.h -- C ABI of libnbody_hip.so, the MI355X (gfx950) force/integration engine.
+ *
+ * This is the drop-in boundary for the hot path of LessUp/n-body: every entry point
+ * replaces one CUDA launch wrapper / class method of the reference (cited per
+ * function as `ref: file:line`, paths relative to the reference checkout).  The
+ * reference itself has no C ABI; its plugin API is the C++ strategy interface
+ * `nbody::ForceCalculator` (include/nbody/force_calculator.hpp:36-89).  The C++
+ * facade in n-body_amd/facade/ re-creates those classes on top of this header;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every `float*` inside nbody_particle_data is a
+ *    DEVICE pointer (hipMalloc'd, caller-owned) unless the function says "host".
+ *  - every call returns 0 on success or a negative nbody_hip_status; the message is
+ *    available from nbody_hip_last_error() (thread-local), formatted like the
+ *    reference's CudaException ("<what> at file:line", error_handling.hpp:29-51).
+ *  - calls are asynchronous on the context's HIP stream unless they return a value
+ *    to the host (energies) or say "blocking".  Not thread-safe per context, like
+ *    the reference (force_calculator.hpp:8-19).
+ *  - no CPU fallback exists: without a HIP device every entry point fails with
+ *    NBODY_HIP_ERR_DEVICE.
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_HIP_ABI_VERSION 1
+
+/* exported with default visibility; everything else in the library is hidden */
+#if defined(__GNUC__)
+#define NBODY_HIP_API __attribute__((visibility("default")))
+#else
+#define NBODY_HIP_API
+#endif
+
+typedef enum nbody_hip_status {
+  NBODY_HIP_OK = 0,
+  NBODY_HIP_ERR_VALIDATION = -1, /* bad argument (ref: ValidationException) */
+  NBODY_HIP_ERR_DEVICE = -2,     /* HIP runtime error (ref: CudaException) */
+  NBODY_HIP_ERR_RESOURCE = -3,   /* out of memory / grid too large (ref: ResourceException) */
+  NBODY_HIP_ERR_STATE = -4       /* call sequence error (NULL handle, not initialised) */
+} nbody_hip_status;
+
+/* ref: ForceMethod, include/nbody/types.hpp:66-70 (same enumerator order) */
+typedef enum nbody_hip_force_method {
+  NBODY_HIP_DIRECT_N2 = 0,
+  NBODY_HIP_BARNES_HUT = 1,
+  NBODY_HIP_SPATIAL_HASH = 2
+} nbody_hip_force_method;
+
+/*
+ * ref: nbody::ParticleData, include/nbody/types.hpp:234-276.  Layout-identical
+ * (13 float* then size_t count, 112 bytes), so a `nbody::ParticleData*` can be
+ * passed straight through the boundary with a reinterpret_cast.
+ */
+typedef struct nbody_particle_data {
+  float* pos_x; float* pos_y; float* pos_z;
+  float* vel_x; float* vel_y; float* vel_z;
+  float* acc_x; float* acc_y; float* acc_z;
+  float* acc_old_x; float* acc_old_y; float* acc_old_z;
+  float* mass;
+  size_t count;
+} nbody_particle_data;
+
+/* 16-byte packed body used by the native (sharded / multi-GPU) entry points:
+ * {x, y, z, mass}.  Accelerations use the same type with w unused. */
+typedef struct nbody_float4 { float x, y, z, w; } nbody_float4;
+
+typedef struct nbody_hip_ctx nbody_hip_ctx;
+
+/* ---- library / context -------------------------------------------------- */
+
+NBODY_HIP_API int nbody_hip_abi_version(void);
+NBODY_HIP_API const char* nbody_hip_last_error(void);
+
+/* Number of HIP devices visible (0 when there is no GPU; never fails). */
+NBODY_HIP_API int nbody_hip_device_count(void);
+
+/* Creates a context on `device`.  `stream` is a hipStream_t the caller owns, or
+ * NULL to let the context create (and own) a non-blocking stream.
+ * ref: the reference uses device 0 / the null stream implicitly (force_direct.cu:93). */
+NBODY_HIP_API int nbody_hip_ctx_create(nbody_hip_ctx** out, int device, void* stream);
+NBODY_HIP_API int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx);
+/* Re-targets later launches to another caller-owned stream (NULL = the context's own). */
+NBODY_HIP_API int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream);
+/* Blocks until all work queued on the context's stream is done.
+ * ref: CUDA_CHECK_KERNEL's debug-mode cudaDeviceSynchronize, error_handling.hpp:124-136 */
+NBODY_HIP_API int nbody_hip_ctx_synchronize(nbody_hip_ctx* ctx);
+
+/* ---- a11: particle memory (ref: ParticleDataManager, src/cuda/particle_init.cu:143-283) */
+
+/* ref: allocateDevice :143-168 -- 13 arrays of `count` floats, accelerations zeroed.
+ * One slab allocation, 256-byte aligned sub-arrays; freed by nbody_hip_particles_free. */
+NBODY_HIP_API int nbody_hip_particles_alloc(nbody_particle_data* d, size_t count);
+/* ref: freeDevice :170-198 -- frees and nulls every pointer, count = 0. */
+NBODY_HIP_API int nbody_hip_particles_free(nbody_particle_data* d);
+/* ref: copyToDevice :257-269 -- host -> device of pos, vel, acc, mass (10 arrays; acc_old is
+ * NOT copied, as in the reference).  Blocking. */
+NBODY_HIP_API int nbody_hip_particles_upload(nbody_particle_data* d, const nbody_particle_data* h);
+/* ref: copyToHost :271-283 -- device -> host of the same 10 arrays.  Blocking. */
+NBODY_HIP_API int nbody_hip_particles_download(nbody_particle_data* h, const nbody_particle_data* d);
+
+/* ---- a4: Direct N^2 (ref: src/cuda/force_direct.cu:10-106) ---------------- */
+
+/* ref: launchDirectForceKernel(ParticleData*, G, eps2, block_size) :88-98.
+ * Reads pos_*, mass; OVERWRITES acc_* with a_i = G * sum_{j != i} m_j r_ij (|r_ij|^2+eps2)^-3/2.
+ * `block_size` is accepted for signature parity and validated (1..1024) but does not pick the
+ * launch shape: tiling is chosen for the 256-CU part from `count`. */
+NBODY_HIP_API int nbody_hip_direct_forces(nbody_hip_ctx* ctx, const nbody_particle_data* d, float G, float eps2,
+                            int block_size);
+
+/* Native form used by the sharded (multi-GPU) path: accelerations of `n_targets` packed
+ * bodies due to `n_sources` packed bodies (targets may be a sub-range of the sources; a
+ * coincident pair contributes exactly zero, which is how the self pair is skipped).
+ * acc_out[i] = {ax, ay, az, 0}.  If `accumulate` is non-zero the result is ADDED to acc_out
+ * (used to overlap the local-shard pass with the all-gather of the remote shards). */
+NBODY_HIP_API int nbody_hip_direct_forces_packed(nbody_hip_ctx* ctx, const nbody_float4* targets,
+                                   size_t n_targets, const nbody_float4* sources,
+                                   size_t n_sources, nbody_float4* acc_out, float G, float eps2,
+                                   int accumulate);
+
+/* SoA <-> packed conversion on device (x,y,z,mass -> float4 and back). */
+NBODY_HIP_API int nbody_hip_pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                        const float* mass, size_t count, nbody_float4* out);
+NBODY_HIP_API int nbody_hip_unpack3(nbody_hip_ctx* ctx, const nbody_float4* in, size_t count, float* x,
+                      float* y, float* z);
+
+/* ---- a6: Velocity Verlet (ref: src/cuda/integrator.cu:11-48,122-152,224-238) */
+
+/* ref: launchUpdatePositionsKernel :122-131   x += v dt + a (dt^2/2) */
+NBODY_HIP_API int nbody_hip_update_positions(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt);
+/* ref: launchUpdateVelocitiesKernel :133-142  v += (a_old + a) (dt/2) */
+NBODY_HIP_API int nbody_hip_update_velocities(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt);
+/* ref: launchStoreAccelerationsKernel :144-152  a_old = a */
+NBODY_HIP_API int nbody_hip_store_accelerations(nbody_hip_ctx* ctx, nbody_particle_data* d);
+/* ref: Integrator::integrate with a DirectForceCalculator :224-238, `steps` times:
+ * one fused drift pass (a_old<-a, x update, float4 pack), the force kernel, and the
+ * velocity update fused into the force reduction epilogue. */
+NBODY_HIP_API int nbody_hip_integrate_direct(nbody_hip_ctx* ctx, nbody_particle_data* d, float G, float eps2,
+                               float dt, int steps);
+
+/* Packed (float4) halves of the same step for the sharded multi-GPU path, where each rank
+ * keeps only its target range: drift = x += v dt + a dt^2/2 on {x,y,z,m}; kick =
+ * v += (a_old + a_new) dt/2.  The caller swaps its two acceleration buffers between steps
+ * (no a_old copy).  ref: integrator.cu:16-19 and :31-34. */
+NBODY_HIP_API int nbody_hip_drift_packed(nbody_hip_ctx* ctx, nbody_float4* posm, const nbody_float4* vel,
+                                         const nbody_float4* acc, size_t count, float dt);
+NBODY_HIP_API int nbody_hip_kick_packed(nbody_hip_ctx* ctx, nbody_float4* vel, const nbody_float4* acc_old,
+                                        const nbody_float4* acc_new, size_t count, float dt);
+
+/* ---- a7: energies (ref: src/cuda/integrator.cu:51-119,252-293) ------------ */
+
+/* ref: Integrator::computeKineticEnergy :252-269 -- 0.5 sum m v^2.  fp64 reduction on device,
+ * result rounded to float like the reference's return type.  Blocking. */
+NBODY_HIP_API int nbody_hip_kinetic_energy(nbody_hip_ctx* ctx, const nbody_particle_data* d, float* out);
+/* ref: Integrator::computePotentialEnergy :271-289 -- -G sum_{i<j} m_i m_j / sqrt(r^2+eps^2).
+ * Takes eps (not eps^2) like the reference.  Blocking. */
+NBODY_HIP_API int nbody_hip_potential_energy(nbody_hip_ctx* ctx, const nbody_particle_data* d, float G,
+                               float eps, float* out);
+/* fp64 variants of the two above (no final rounding to float). */
+NBODY_HIP_API int nbody_hip_kinetic_energy_f64(nbody_hip_ctx* ctx, const nbody_particle_data* d, double* out);
+NBODY_HIP_API int nbody_hip_potential_energy_f64(nbody_hip_ctx* ctx, const nbody_particle_data* d, float G,
+                                   float eps, double* out);
+
+/* ---- measurement helpers -------------------------------------------------- */
+
+/* Runs the direct-force kernel `iters` times back to back on the context's stream between
+ * two HIP events and returns the mean milliseconds per launch (blocking).  bench.py's
+ * `roofline.achieved` comes from this; rocprofv3's kernel trace must agree. */
+NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_float4* targets,
+                                 size_t n_targets, const nbody_float4* sources, size_t n_sources,
+                                 nbody_float4* acc_out, float G, float eps2, int iters,
+                                 float* ms_per_launch);
+
+/* Tuning knobs for experiments (0 = automatic).  variant: kernel body variant id;
+ * targets_per_lane: 1, 2 or 4; source_splits: number of source sub-ranges per target block. */
+NBODY_HIP_API int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
+                            int source_splits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

@@ -1,0 +1,14 @@
+"""n-body_amd -- MI355X-native force/integration engine behind the LessUp/n-body plugin API.
+
+The directory name contains a hyphen (it mirrors the reference's repository name), so the
+package is imported under the module name `nbody_amd`; tests/conftest.py, bench.py and
+__graft_entry__.py register it with `load_package()` from the repo-root helper `nbody_amd.py`.
+"""
+from . import _lib, ic  # noqa: F401
+from ._lib import (DeviceException, NBodyError, ResourceException, StateException,  # noqa: F401
+                   ValidationException)
+from .api import *  # noqa: F401,F403
+from .api import (Context, DirectForceCalculator, ForceCalculator, ForceMethod,  # noqa: F401
+                  InitDistribution, Integrator, ParticleData, ParticleDataManager,
+                  SimulationConfig, createForceCalculator, default_context,
+                  direct_forces_packed, pack_posm, time_direct_packed)

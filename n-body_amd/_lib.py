@@ -1,0 +1,114 @@
+"""ctypes binding of libnbody_hip.so (the C ABI declared in include/nbody_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, or no HIP device is
+present when a context is created, the call raises.  Nothing here imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnbody_hip.so")
+
+# status codes (include/nbody_hip.h: nbody_hip_status)
+OK, ERR_VALIDATION, ERR_DEVICE, ERR_RESOURCE, ERR_STATE = 0, -1, -2, -3, -4
+
+
+class NBodyError(RuntimeError):
+    """Base of the errors raised from the C ABI (ref: include/nbody/error_handling.hpp:29-102)."""
+
+
+class ValidationException(NBodyError, ValueError):
+    """ref: nbody::ValidationException"""
+
+
+class DeviceException(NBodyError):
+    """ref: nbody::CudaException (HIP runtime error here)"""
+
+
+class ResourceException(NBodyError, MemoryError):
+    """ref: nbody::ResourceException"""
+
+
+class StateException(NBodyError):
+    """call-sequence error (null handle / missing arrays)"""
+
+
+_EXC = {ERR_VALIDATION: ValidationException, ERR_DEVICE: DeviceException,
+        ERR_RESOURCE: ResourceException, ERR_STATE: StateException}
+
+
+class ParticleDataStruct(C.Structure):
+    """Layout-identical to nbody::ParticleData (include/nbody/types.hpp:234-276)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "acc_x", "acc_y", "acc_z",
+        "acc_old_x", "acc_old_y", "acc_old_z", "mass")] + [("count", C.c_size_t)]
+
+
+FIELDS = tuple(n for n, _ in ParticleDataStruct._fields_[:13])
+
+# every symbol include/nbody_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PD = C.POINTER(ParticleDataStruct)
+PROTOTYPES = {
+    "nbody_hip_abi_version": (C.c_int, []),
+    "nbody_hip_last_error": (C.c_char_p, []),
+    "nbody_hip_device_count": (C.c_int, []),
+    "nbody_hip_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, _P]),
+    "nbody_hip_ctx_destroy": (C.c_int, [_P]),
+    "nbody_hip_ctx_set_stream": (C.c_int, [_P, _P]),
+    "nbody_hip_ctx_synchronize": (C.c_int, [_P]),
+    "nbody_hip_particles_alloc": (C.c_int, [_PD, C.c_size_t]),
+    "nbody_hip_particles_free": (C.c_int, [_PD]),
+    "nbody_hip_particles_upload": (C.c_int, [_PD, _PD]),
+    "nbody_hip_particles_download": (C.c_int, [_PD, _PD]),
+    "nbody_hip_direct_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_int]),
+    "nbody_hip_direct_forces_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P,
+                                                 C.c_float, C.c_float, C.c_int]),
+    "nbody_hip_pack_posm": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "nbody_hip_unpack3": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
+    "nbody_hip_update_positions": (C.c_int, [_P, _PD, C.c_float]),
+    "nbody_hip_update_velocities": (C.c_int, [_P, _PD, C.c_float]),
+    "nbody_hip_store_accelerations": (C.c_int, [_P, _PD]),
+    "nbody_hip_integrate_direct": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "nbody_hip_drift_packed": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float]),
+    "nbody_hip_kick_packed": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float]),
+    "nbody_hip_kinetic_energy": (C.c_int, [_P, _PD, C.POINTER(C.c_float)]),
+    "nbody_hip_potential_energy": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.POINTER(C.c_float)]),
+    "nbody_hip_kinetic_energy_f64": (C.c_int, [_P, _PD, C.POINTER(C.c_double)]),
+    "nbody_hip_potential_energy_f64": (C.c_int, [_P, _PD, C.c_float, C.c_float,
+                                                 C.POINTER(C.c_double)]),
+    "nbody_hip_time_direct_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_float,
+                                               C.c_float, C.c_int, C.POINTER(C.c_float)]),
+    "nbody_hip_direct_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libnbody_hip.so (once).  Raises ImportError with the build hint if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C n-body_amd/csrc` (hipcc, gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nbody_hip_abi_version() != 1:
+        raise ImportError("libnbody_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc == OK:
+        return
+    msg = load().nbody_hip_last_error().decode("utf-8", "replace")
+    raise _EXC.get(rc, NBodyError)(msg)

@@ -1,0 +1,432 @@
+"""Host-side mirror of the reference's C++ interface for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference headers so that the parity
+tests read like the reference's own tests:
+
+  ParticleData / ParticleDataManager    include/nbody/types.hpp:234-276, particle_data.hpp:9-36
+  ForceCalculator / DirectForceCalculator / createForceCalculator
+                                        include/nbody/force_calculator.hpp:36-231
+  Integrator                            include/nbody/integrator.hpp:51-150
+  SimulationConfig / ForceMethod        include/nbody/types.hpp:66-101,301-313
+  validate*                             src/utils/error_handling.cpp:46-123
+
+PyTorch is used only as the owner of device memory and of the HIP stream; every computation is
+a call into libnbody_hip.so.  The compiled-language facade (C++) lives in n-body_amd/facade/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (FIELDS, ParticleDataStruct, ValidationException, check)
+
+
+class ForceMethod(enum.IntEnum):  # types.hpp:66-70
+    DIRECT_N2 = 0
+    BARNES_HUT = 1
+    SPATIAL_HASH = 2
+
+
+class InitDistribution(enum.IntEnum):  # types.hpp:82-86
+    UNIFORM = 0
+    SPHERICAL = 1
+    DISK = 2
+
+
+@dataclass
+class SimulationConfig:  # types.hpp:301-313 (same defaults)
+    particle_count: int = 10000
+    init_distribution: InitDistribution = InitDistribution.SPHERICAL
+    force_method: ForceMethod = ForceMethod.DIRECT_N2
+    dt: float = 0.001
+    G: float = 1.0
+    softening: float = 0.1
+    barnes_hut_theta: float = 0.5
+    spatial_hash_cell_size: float = 1.0
+    spatial_hash_cutoff: float = 2.0
+    cuda_block_size: int = 256
+
+
+# ---- validators (error_handling.cpp:46-123; same messages) ------------------------------------
+
+def _finite(v):
+    return not (math.isnan(v) or math.isinf(v))
+
+
+def validateParticleCountRange(count):
+    if count == 0:
+        raise ValidationException("Particle count must be greater than 0")
+    if count > 100000000:
+        raise ValidationException("Particle count exceeds maximum supported (100M)")
+
+
+def validateTimeStep(dt):  # same check order as error_handling.cpp:91-103
+    if dt <= 0:
+        raise ValidationException("Time step must be positive")
+    if math.isnan(dt) or math.isinf(dt):
+        raise ValidationException("Time step must be a finite number")
+    if dt > 1.0:
+        raise ValidationException("Time step is too large (max 1.0)")
+
+
+def validateSoftening(eps):  # error_handling.cpp:105-113
+    if eps < 0:
+        raise ValidationException("Softening parameter must be non-negative")
+    if math.isnan(eps) or math.isinf(eps):
+        raise ValidationException("Softening parameter must be a finite number")
+
+
+def validateTheta(theta):  # error_handling.cpp:115-123
+    if theta < 0 or theta > 2.0:
+        raise ValidationException("Barnes-Hut theta must be between 0 and 2")
+    if math.isnan(theta) or math.isinf(theta):
+        raise ValidationException("Barnes-Hut theta must be a finite number")
+
+
+def validateSimulationConfig(cfg: SimulationConfig):
+    validateParticleCountRange(cfg.particle_count)
+    validateTimeStep(cfg.dt)
+    validateSoftening(cfg.softening)
+    if cfg.force_method == ForceMethod.BARNES_HUT:
+        validateTheta(cfg.barnes_hut_theta)
+    if cfg.G <= 0 or not _finite(cfg.G):
+        raise ValidationException("Gravitational constant must be positive and finite")
+    if cfg.force_method == ForceMethod.SPATIAL_HASH:
+        if cfg.spatial_hash_cell_size <= 0 or not _finite(cfg.spatial_hash_cell_size):
+            raise ValidationException("Spatial hash cell size must be positive and finite")
+        if cfg.spatial_hash_cutoff <= 0 or not _finite(cfg.spatial_hash_cutoff):
+            raise ValidationException("Spatial hash cutoff must be positive and finite")
+    if cfg.cuda_block_size <= 0 or cfg.cuda_block_size > 1024:
+        raise ValidationException("CUDA block size must be between 1 and 1024")
+
+
+# ---- context -------------------------------------------------------------------------------
+
+class Context:
+    """One per (process, device).  Launches go to torch's current stream of that device so that
+    torch.cuda events / synchronize() order against them."""
+
+    def __init__(self, device: int | None = None):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.DeviceException("no HIP device available (this library has no CPU fallback)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        stream = torch.cuda.current_stream(self.torch_device).cuda_stream
+        h = C.c_void_p()
+        check(lib.nbody_hip_ctx_create(C.byref(h), self.device, C.c_void_p(stream)))
+        self._h = h
+        self._lib = lib
+
+    @property
+    def handle(self):
+        return self._h
+
+    def use_stream(self, stream: "torch.cuda.Stream | None"):
+        ptr = None if stream is None else C.c_void_p(stream.cuda_stream)
+        check(self._lib.nbody_hip_ctx_set_stream(self._h, ptr))
+
+    def synchronize(self):
+        check(self._lib.nbody_hip_ctx_synchronize(self._h))
+
+    def tuning(self, variant=0, targets_per_lane=0, source_splits=0):
+        check(self._lib.nbody_hip_direct_tuning(self._h, variant, targets_per_lane, source_splits))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nbody_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ---- particle data ---------------------------------------------------------------------------
+
+class ParticleData:
+    """13 float32 arrays + count (types.hpp:234-276).  `where` is "device" (torch tensors on the
+    GPU) or "host" (numpy arrays)."""
+
+    def __init__(self):
+        self.count = 0
+        self.where = None
+        for f in FIELDS:
+            setattr(self, f, None)
+
+    def struct(self) -> ParticleDataStruct:
+        s = ParticleDataStruct()
+        for f in FIELDS:
+            a = getattr(self, f)
+            if a is None:
+                ptr = None
+            elif isinstance(a, torch.Tensor):
+                ptr = a.data_ptr()
+            else:
+                ptr = a.ctypes.data
+            setattr(s, f, ptr)
+        s.count = self.count
+        return s
+
+
+class ParticleDataManager:
+    """particle_data.hpp:9-36 / particle_init.cu:143-283."""
+
+    @staticmethod
+    def allocateDevice(data: ParticleData, count: int, device=None):
+        validateParticleCountRange(count)
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        # one slab, 64-float (256 B) aligned sub-arrays, zero-initialised (ref zeroes acc*)
+        stride = (count + 63) // 64 * 64
+        slab = torch.zeros(13 * stride, dtype=torch.float32, device=dev)
+        for k, f in enumerate(FIELDS):
+            setattr(data, f, slab[k * stride:k * stride + count])
+        data._slab = slab
+        data.count = count
+        data.where = "device"
+
+    @staticmethod
+    def freeDevice(data: ParticleData):
+        for f in FIELDS:
+            setattr(data, f, None)
+        data._slab = None
+        data.count = 0
+
+    @staticmethod
+    def allocateHost(data: ParticleData, count: int):
+        for f in FIELDS:
+            setattr(data, f, np.zeros(count, dtype=np.float32))
+        data.count = count
+        data.where = "host"
+
+    @staticmethod
+    def freeHost(data: ParticleData):
+        for f in FIELDS:
+            setattr(data, f, None)
+        data.count = 0
+
+    _COPIED = ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "acc_x", "acc_y", "acc_z",
+               "mass")  # acc_old is not copied by the reference either (particle_init.cu:257-283)
+
+    @staticmethod
+    def copyToDevice(d_data: ParticleData, h_data: ParticleData):
+        if h_data.count > d_data.count:
+            raise ValidationException("host count exceeds device capacity")
+        n = h_data.count
+        for f in ParticleDataManager._COPIED:
+            getattr(d_data, f)[:n].copy_(torch.from_numpy(np.ascontiguousarray(getattr(h_data, f)[:n])))
+
+    @staticmethod
+    def copyToHost(h_data: ParticleData, d_data: ParticleData):
+        if d_data.count > h_data.count:
+            raise ValidationException("device count exceeds host capacity")
+        n = d_data.count
+        for f in ParticleDataManager._COPIED:
+            getattr(h_data, f)[:n] = getattr(d_data, f)[:n].cpu().numpy()
+
+
+# ---- force calculators -----------------------------------------------------------------------
+
+class ForceCalculator:
+    """force_calculator.hpp:36-89: caches eps, eps^2, G; computeForces overwrites acc_*."""
+
+    def __init__(self, ctx: Context | None = None):
+        self.softening_eps_ = 0.01
+        self.softening_eps2_ = 0.0001
+        self.G_ = 1.0
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def setSofteningParameter(self, eps):
+        self.softening_eps_ = float(eps)
+        # eps*eps in fp32, as the C++ setter does with float members
+        self.softening_eps2_ = float(np.float32(eps) * np.float32(eps))
+
+    def setGravitationalConstant(self, G):
+        self.G_ = float(G)
+
+    def getSofteningParameter(self):
+        return self.softening_eps_
+
+    def getGravitationalConstant(self):
+        return self.G_
+
+    def computeForces(self, d_particles: ParticleData):
+        raise NotImplementedError
+
+    def getMethod(self) -> ForceMethod:
+        raise NotImplementedError
+
+
+class DirectForceCalculator(ForceCalculator):
+    """force_calculator.hpp:101-121 / force_direct.cu:101-106."""
+
+    def __init__(self, block_size: int = 256, ctx: Context | None = None):
+        super().__init__(ctx)
+        self.block_size_ = block_size
+
+    def computeForces(self, d_particles: ParticleData):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_direct_forces(self.ctx.handle, C.byref(s), self.G_,
+                                                    self.softening_eps2_, self.block_size_))
+
+    def getMethod(self):
+        return ForceMethod.DIRECT_N2
+
+    def setBlockSize(self, size):
+        self.block_size_ = size
+
+    def getBlockSize(self):
+        return self.block_size_
+
+
+def createForceCalculator(method: ForceMethod, config: SimulationConfig,
+                          ctx: Context | None = None) -> ForceCalculator:
+    """force_spatial_hash.cu:380-401: unknown enumerators fall back to Direct."""
+    if method == ForceMethod.BARNES_HUT or method == ForceMethod.SPATIAL_HASH:
+        raise NotImplementedError(f"{ForceMethod(method).name} is not built yet in this tree")
+    calc = DirectForceCalculator(config.cuda_block_size, ctx)
+    calc.setGravitationalConstant(config.G)
+    calc.setSofteningParameter(config.softening)
+    return calc
+
+
+# ---- integrator ------------------------------------------------------------------------------
+
+class Integrator:
+    """integrator.hpp:51-150 / integrator.cu:224-293."""
+
+    def __init__(self, block_size: int = 256, ctx: Context | None = None):
+        self.block_size_ = block_size
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def integrate(self, d_particles: ParticleData, force_calc: ForceCalculator, dt: float):
+        # integrator.cu:224-238
+        if isinstance(force_calc, DirectForceCalculator):
+            s = d_particles.struct()
+            check(self.ctx._lib.nbody_hip_integrate_direct(
+                self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, 1))
+            return
+        self.storeOldAccelerations(d_particles)
+        self.updatePositions(d_particles, dt)
+        force_calc.computeForces(d_particles)
+        self.updateVelocities(d_particles, dt)
+
+    def integrate_steps(self, d_particles, force_calc: DirectForceCalculator, dt: float, steps: int):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_integrate_direct(
+            self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, steps))
+
+    def updatePositions(self, d_particles, dt):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_update_positions(self.ctx.handle, C.byref(s), dt))
+
+    def updateVelocities(self, d_particles, dt):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_update_velocities(self.ctx.handle, C.byref(s), dt))
+
+    def storeOldAccelerations(self, d_particles):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_store_accelerations(self.ctx.handle, C.byref(s)))
+
+    def computeKineticEnergy(self, d_particles) -> float:
+        s = d_particles.struct()
+        out = C.c_float()
+        check(self.ctx._lib.nbody_hip_kinetic_energy(self.ctx.handle, C.byref(s), C.byref(out)))
+        return out.value
+
+    def computePotentialEnergy(self, d_particles, G, eps) -> float:
+        s = d_particles.struct()
+        out = C.c_float()
+        check(self.ctx._lib.nbody_hip_potential_energy(self.ctx.handle, C.byref(s), G, eps,
+                                                       C.byref(out)))
+        return out.value
+
+    def computeTotalEnergy(self, d_particles, G, eps) -> float:
+        # integrator.cu:291-293: fp32 sum of the two
+        return float(np.float32(self.computeKineticEnergy(d_particles)) +
+                     np.float32(self.computePotentialEnergy(d_particles, G, eps)))
+
+    def computeEnergiesF64(self, d_particles, G, eps):
+        s = d_particles.struct()
+        ke, pe = C.c_double(), C.c_double()
+        check(self.ctx._lib.nbody_hip_kinetic_energy_f64(self.ctx.handle, C.byref(s), C.byref(ke)))
+        check(self.ctx._lib.nbody_hip_potential_energy_f64(self.ctx.handle, C.byref(s), G, eps,
+                                                           C.byref(pe)))
+        return ke.value, pe.value
+
+    def setBlockSize(self, size):
+        self.block_size_ = size
+
+    def getBlockSize(self):
+        return self.block_size_
+
+
+# ---- packed (native) entry points ------------------------------------------------------------
+
+def pack_posm(ctx: Context, x, y, z, m) -> torch.Tensor:
+    n = x.numel()
+    out = torch.empty((n, 4), dtype=torch.float32, device=x.device)
+    check(ctx._lib.nbody_hip_pack_posm(ctx.handle, x.data_ptr(), y.data_ptr(), z.data_ptr(),
+                                       m.data_ptr(), n, out.data_ptr()))
+    return out
+
+
+def direct_forces_packed(ctx: Context, targets: torch.Tensor, sources: torch.Tensor, G: float,
+                         eps2: float, out: torch.Tensor | None = None, accumulate: bool = False):
+    """targets [nt,4], sources [ns,4] float32 contiguous on the device -> acc [nt,4]."""
+    assert targets.dtype == torch.float32 and sources.dtype == torch.float32
+    assert targets.is_contiguous() and sources.is_contiguous()
+    assert targets.dim() == 2 and targets.shape[1] == 4 and sources.dim() == 2 and sources.shape[1] == 4
+    nt, ns = targets.shape[0], sources.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((nt, 4), dtype=torch.float32, device=targets.device)
+    assert out.is_contiguous() and out.shape == (nt, 4)
+    check(ctx._lib.nbody_hip_direct_forces_packed(ctx.handle, targets.data_ptr(), nt,
+                                                  sources.data_ptr(), ns, out.data_ptr(), G, eps2,
+                                                  1 if accumulate else 0))
+    return out
+
+
+def time_direct_packed(ctx: Context, targets, sources, G, eps2, iters: int, out=None) -> float:
+    nt, ns = targets.shape[0], sources.shape[0]
+    if out is None:
+        out = torch.empty((nt, 4), dtype=torch.float32, device=targets.device)
+    ms = C.c_float()
+    check(ctx._lib.nbody_hip_time_direct_packed(ctx.handle, targets.data_ptr(), nt,
+                                                sources.data_ptr(), ns, out.data_ptr(), G, eps2,
+                                                iters, C.byref(ms)))
+    return ms.value

@@ -1,0 +1,314 @@
+// api.hip -- context, error reporting, particle memory and the Direct-N^2 entry points of the
+// C ABI declared in include/nbody_hip.h.
+
+#include <cstdarg>
+#include <cstring>
+
+#include "common.h"
+
+namespace nbh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(nbody_hip_status code, const char* file, int line, const char* fmt, ...) {
+  char msg[384];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(msg, sizeof(msg), fmt, ap);
+  va_end(ap);
+  const char* base = strrchr(file, '/');
+  snprintf(g_err, sizeof(g_err), "%s at %s:%d", msg, base ? base + 1 : file, line);
+  return (int)code;
+}
+
+int Workspace::reserve(size_t want) {
+  if (want <= bytes) return NBODY_HIP_OK;
+  // grow geometrically so a slowly growing problem does not reallocate every call
+  size_t cap = bytes + bytes / 2;
+  if (cap < want) cap = want;
+  cap = (cap + 255) & ~(size_t)255;
+  void* p = nullptr;
+  NBH_HIP(hipMalloc(&p, cap));
+  if (ptr) {
+    // queued work may still read the old buffer
+    NBH_HIP(hipDeviceSynchronize());
+    NBH_HIP(hipFree(ptr));
+  }
+  ptr = p;
+  bytes = cap;
+  return NBODY_HIP_OK;
+}
+
+void Workspace::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+}  // namespace nbh
+
+using namespace nbh;
+
+extern "C" int nbody_hip_abi_version(void) { return NBODY_HIP_ABI_VERSION; }
+
+extern "C" const char* nbody_hip_last_error(void) { return g_err; }
+
+extern "C" int nbody_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int nbody_hip_ctx_create(nbody_hip_ctx** out, int device, void* stream) {
+  if (!out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null output pointer");
+  *out = nullptr;
+  const int ndev = nbody_hip_device_count();
+  if (ndev <= 0)
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "device %d out of range [0,%d)", device, ndev);
+  NBH_HIP(hipSetDevice(device));
+  nbody_hip_ctx* c = new nbody_hip_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+  }
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_scalar), 4 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    nbody_hip_ctx_destroy(c);
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "context resources: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx) {
+  if (!ctx) return NBODY_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->posm.release();
+  ctx->partial.release();
+  ctx->reduce.release();
+  if (ctx->host_scalar) (void)hipHostFree(ctx->host_scalar);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (!ctx->own_stream) {
+      NBH_HIP(hipSetDevice(ctx->device));
+      NBH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    }
+    ctx->stream = ctx->own_stream;
+  }
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_ctx_synchronize(nbody_hip_ctx* ctx) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  NBH_HIP(hipSetDevice(ctx->device));
+  NBH_HIP(hipStreamSynchronize(ctx->stream));
+  return NBODY_HIP_OK;
+}
+
+// ---- particle memory -------------------------------------------------------------------
+
+static inline float** field(nbody_particle_data* d, int k) { return &d->pos_x + k; }
+static inline float* const* cfield(const nbody_particle_data* d, int k) { return &d->pos_x + k; }
+
+extern "C" int nbody_hip_particles_alloc(nbody_particle_data* d, size_t count) {
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (count == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (count > 100000000u)  // ref: validateParticleCountRange, error_handling.cpp:76-84
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count exceeds maximum supported (100M)");
+  if (nbody_hip_device_count() <= 0)
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  // One slab, 13 sub-arrays each padded to 256 B: one allocation instead of the reference's 13
+  // (particle_init.cu:147-159) and every array 16-byte aligned for dwordx4 access.
+  const size_t stride = ((count * sizeof(float)) + 255) & ~(size_t)255;
+  char* base = nullptr;
+  NBH_HIP(hipMalloc(reinterpret_cast<void**>(&base), stride * 13));
+  // ref zeroes the six acceleration arrays (:161-166); zero everything so that no field is
+  // ever uninitialised device memory.
+  hipError_t e = hipMemset(base, 0, stride * 13);
+  if (e != hipSuccess) {
+    (void)hipFree(base);
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "hipMemset: %s", hipGetErrorString(e));
+  }
+  for (int k = 0; k < 13; k++) *field(d, k) = reinterpret_cast<float*>(base + stride * k);
+  d->count = count;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_particles_free(nbody_particle_data* d) {
+  if (!d) return NBODY_HIP_OK;
+  if (d->pos_x) {
+    NBH_HIP(hipDeviceSynchronize());
+    NBH_HIP(hipFree(d->pos_x));  // slab base
+  }
+  for (int k = 0; k < 13; k++) *field(d, k) = nullptr;
+  d->count = 0;
+  return NBODY_HIP_OK;
+}
+
+// the 10 arrays the reference copies (particle_init.cu:257-283): pos, vel, acc, mass
+static const int kCopied[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 12};
+
+extern "C" int nbody_hip_particles_upload(nbody_particle_data* d, const nbody_particle_data* h) {
+  if (!d || !h) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (h->count > d->count)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "host count %zu exceeds device capacity %zu", h->count, d->count);
+  const size_t bytes = h->count * sizeof(float);
+  for (int k : kCopied) {
+    if (!*cfield(h, k) || !*cfield(d, k)) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null array in particle data");
+    NBH_HIP(hipMemcpy(*field(d, k), *cfield(h, k), bytes, hipMemcpyHostToDevice));
+  }
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_particles_download(nbody_particle_data* h, const nbody_particle_data* d) {
+  if (!d || !h) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (d->count > h->count)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "device count %zu exceeds host capacity %zu", d->count, h->count);
+  const size_t bytes = d->count * sizeof(float);
+  for (int k : kCopied) {
+    if (!*cfield(h, k) || !*cfield(d, k)) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null array in particle data");
+    NBH_HIP(hipMemcpy(*field(h, k), *cfield(d, k), bytes, hipMemcpyDeviceToHost));
+  }
+  return NBODY_HIP_OK;
+}
+
+// ---- Direct N^2 ------------------------------------------------------------------------
+
+extern "C" int nbody_hip_pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y,
+                                   const float* z, const float* mass, size_t count,
+                                   nbody_float4* out) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (count == 0) return NBODY_HIP_OK;
+  if (!x || !y || !z || !mass || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (count > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");
+  NBH_HIP(hipSetDevice(ctx->device));
+  return pack_posm(ctx, x, y, z, mass, count, reinterpret_cast<float4*>(out));
+}
+
+namespace nbh {
+__global__ __launch_bounds__(kBlock) void unpack3_kernel(const float4* __restrict__ in, int n,
+                                                         float* __restrict__ x,
+                                                         float* __restrict__ y,
+                                                         float* __restrict__ z) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    const float4 v = in[i];
+    x[i] = v.x; y[i] = v.y; z[i] = v.z;
+  }
+}
+}  // namespace nbh
+
+extern "C" int nbody_hip_unpack3(nbody_hip_ctx* ctx, const nbody_float4* in, size_t count, float* x,
+                                 float* y, float* z) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (count == 0) return NBODY_HIP_OK;
+  if (!x || !y || !z || !in) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (count > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");
+  NBH_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(unpack3_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, ctx->stream, reinterpret_cast<const float4*>(in), (int)count, x, y, z);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_direct_forces(nbody_hip_ctx* ctx, const nbody_particle_data* d, float G,
+                                       float eps2, int block_size) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (block_size <= 0 || block_size > 1024)  // ref: validateSimulationConfig, error_handling.cpp:70-72
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "CUDA block size must be between 1 and 1024");
+  const size_t n = d->count;
+  if (n == 0) return NBODY_HIP_OK;
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass || !d->acc_x || !d->acc_y || !d->acc_z)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  if (n > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");
+  NBH_HIP(hipSetDevice(ctx->device));
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
+  return direct_packed(ctx, posm, n, posm, n, G, eps2, nullptr, 0, d->acc_x, d->acc_y, d->acc_z,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+}
+
+extern "C" int nbody_hip_direct_forces_packed(nbody_hip_ctx* ctx, const nbody_float4* targets,
+                                              size_t n_targets, const nbody_float4* sources,
+                                              size_t n_sources, nbody_float4* acc_out, float G,
+                                              float eps2, int accumulate) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (n_targets == 0) return NBODY_HIP_OK;
+  if (!targets || !acc_out || (n_sources > 0 && !sources))
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  NBH_HIP(hipSetDevice(ctx->device));
+  return direct_packed(ctx, reinterpret_cast<const float4*>(targets), n_targets,
+                       reinterpret_cast<const float4*>(sources), n_sources, G, eps2,
+                       reinterpret_cast<float4*>(acc_out), accumulate, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+}
+
+extern "C" int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_float4* targets,
+                                            size_t n_targets, const nbody_float4* sources,
+                                            size_t n_sources, nbody_float4* acc_out, float G,
+                                            float eps2, int iters, float* ms_per_launch) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (!ms_per_launch || iters <= 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "bad timing arguments");
+  NBH_HIP(hipSetDevice(ctx->device));
+  // one untimed call so that workspace growth is outside the timed region
+  if (int rc = nbody_hip_direct_forces_packed(ctx, targets, n_targets, sources, n_sources, acc_out, G, eps2, 0))
+    return rc;
+  NBH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < iters; i++)
+    if (int rc = nbody_hip_direct_forces_packed(ctx, targets, n_targets, sources, n_sources, acc_out, G, eps2, 0))
+      return rc;
+  NBH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  NBH_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  NBH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_per_launch = ms / (float)iters;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
+                                       int source_splits) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (variant < 0 || variant > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "variant must be 0, 1 or 2");
+  if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "targets_per_lane must be 0 (auto), 1, 2 or 4");
+  if (source_splits < 0 || source_splits > 4096)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "source_splits must be in [0, 4096]");
+  ctx->tune_variant = variant;
+  ctx->tune_tpl = targets_per_lane;
+  ctx->tune_splits = source_splits;
+  return NBODY_HIP_OK;
+}

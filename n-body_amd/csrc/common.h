@@ -1,0 +1,77 @@
+// common.h -- internal declarations shared by the HIP translation units of libnbody_hip.so.
+// gfx950 (MI355X) only; wave64; no CUDA compatibility layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "nbody_hip.h"
+
+namespace nbh {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
+constexpr int kNumCU = 256;   // MI355X
+
+void set_error(const char* fmt, ...);
+int fail(nbody_hip_status code, const char* file, int line, const char* fmt, ...);
+
+#define NBH_FAIL(code, ...) ::nbh::fail((code), __FILE__, __LINE__, __VA_ARGS__)
+
+// HIP call that turns an error into NBODY_HIP_ERR_DEVICE (or _RESOURCE for OOM),
+// message "<call>: <hip error string> at file:line" (ref: CUDA_CHECK, error_handling.hpp:104-114)
+#define NBH_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      return ::nbh::fail(e_ == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE                   \
+                                                   : NBODY_HIP_ERR_DEVICE,                    \
+                         __FILE__, __LINE__, "%s: %s", #call, hipGetErrorString(e_));         \
+    }                                                                                         \
+  } while (0)
+
+// After a kernel launch (ref: CUDA_CHECK_KERNEL, error_handling.hpp:116-136; no sync in release)
+#define NBH_LAUNCH_CHECK() NBH_HIP(hipGetLastError())
+
+struct Workspace {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t want);  // grows (never shrinks); returns status
+  void release();
+};
+
+}  // namespace nbh
+
+struct nbody_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;      // stream launches go to
+  hipStream_t own_stream = nullptr;  // created by the context (may be null)
+  nbh::Workspace posm;               // packed {x,y,z,m} of the bodies        (direct, energy)
+  nbh::Workspace partial;            // per-source-split partial accelerations (direct)
+  nbh::Workspace reduce;             // block partials for energy reductions
+  double* host_scalar = nullptr;     // pinned, 4 doubles
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // tuning overrides (0 = automatic)
+  int tune_variant = 0, tune_tpl = 0, tune_splits = 0;
+};
+
+namespace nbh {
+
+// direct.hip
+int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
+                  const float4* sources, size_t n_sources, float G, float eps2,
+                  // output selection (exactly one of acc4 / soa is used)
+                  float4* acc4, int accumulate, float* ax, float* ay, float* az,
+                  // optional fused velocity update (soa output only): v += (a_old + a) * half_dt
+                  float* vx, float* vy, float* vz, const float* aox, const float* aoy,
+                  const float* aoz, float half_dt);
+int pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m,
+              size_t n, float4* out);
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace nbh

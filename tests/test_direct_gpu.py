@@ -1,0 +1,229 @@
+"""Parity of the HIP Direct-N^2 path (through the C ABI) with the CPU oracle.
+
+Tolerance (BASELINE.json north_star): accelerations within 1e-5 RELATIVE of the CPU reference,
+measured per body as ||a_gpu - a_ref|| / ||a_ref|| against the fp64-accumulated oracle
+(mode 1: the reference's fp32 pair arithmetic without its summation-order noise)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import acc_of, packed, rel_err, to_device
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plummer4096_direct.npz")
+
+
+# mirrors DirectForceCalculatorTest.ComputeForces (tests/test_force_calculation.cpp:62-96):
+# N=100 sphere R=5, G=1, eps=0.1 -> finite accelerations; plus numeric parity, which the
+# reference never checks.
+def test_compute_forces_reference_case(nb, oracle, ctx):
+    ic = nb.ic.sphere(100, seed=42, radius=5.0)
+    d, h = to_device(nb, ic)
+    calc = nb.DirectForceCalculator(256)
+    calc.setGravitationalConstant(1.0)
+    calc.setSofteningParameter(0.1)
+    calc.computeForces(d)
+    nb.ParticleDataManager.copyToHost(h, d)
+    a = np.stack([h.acc_x, h.acc_y, h.acc_z], 1)
+    assert np.all(np.isfinite(a))
+    ref = np.stack(oracle.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                        calc.softening_eps2_, 1), 1)
+    assert rel_err(a, ref).max() < TOL
+
+
+# BASELINE.json config 1 against the committed golden vectors
+def test_golden_plummer4096(nb, ctx):
+    g = np.load(GOLD)
+    ic = {k: g[k] for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
+    d, _ = to_device(nb, ic)
+    calc = nb.DirectForceCalculator()
+    calc.setSofteningParameter(float(g["eps"]))
+    calc.setGravitationalConstant(float(g["G"]))
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert rel_err(a, g["acc_f64acc"]).max() < TOL
+    assert rel_err(a, g["acc_gold"]).max() < TOL
+    # the reference loop's own fp32 sequential sum is itself only ~4e-6 from gold here
+    assert rel_err(a, g["acc_f32seq"]).max() < 2e-5
+
+
+# every kernel variant x targets-per-lane x split count, ragged N
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("tpl", [1, 2, 4])
+@pytest.mark.parametrize("splits", [0, 1, 3])
+def test_variants_agree_with_oracle(nb, oracle, ctx, variant, tpl, splits):
+    if variant == 1 and tpl == 1:
+        pytest.skip("packed body needs two targets per lane")
+    n = 3001
+    ic = nb.ic.plummer(n, seed=3)
+    ref = np.stack(oracle.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0, 1e-6, 1), 1)
+    p = packed(ic)
+    try:
+        ctx.tuning(variant, tpl, splits)
+        a = nb.direct_forces_packed(ctx, p, p, 1.0, 1e-6)
+        torch.cuda.synchronize()
+    finally:
+        ctx.tuning(0, 0, 0)
+    a = a.cpu().numpy()
+    assert np.all(a[:, 3] == 0)
+    assert rel_err(a[:, :3], ref).max() < TOL
+
+
+# BASELINE.json config 2: N=262,144 Plummer, eps=1e-3, sampled targets vs the oracle
+def test_config2_262144_sampled(nb, oracle, ctx):
+    n = 262144
+    ic = nb.ic.plummer(n, seed=42)
+    eps2 = float(np.float32(1e-3) * np.float32(1e-3))
+    d, _ = to_device(nb, ic)
+    calc = nb.DirectForceCalculator()
+    calc.setSofteningParameter(1e-3)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert np.all(np.isfinite(a))
+    rng = np.random.default_rng(0)
+    r = np.sqrt(ic["pos_x"] ** 2 + ic["pos_y"] ** 2 + ic["pos_z"] ** 2)
+    idx = np.unique(np.concatenate([rng.choice(n, 1536, replace=False),
+                                    np.argsort(r)[:256],      # the core: strongest cancellation
+                                    np.argsort(r)[-256:]]))   # the halo
+    ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"],
+                                                idx, 1.0, eps2, 1), 1)
+    e = rel_err(a[idx], ref)
+    assert e.max() < TOL, (e.max(), np.sqrt((e ** 2).mean()))
+
+
+def test_edge_cases(nb, oracle, ctx):
+    calc = nb.DirectForceCalculator()
+    # N = 1: no partner, zero acceleration
+    d, _ = to_device(nb, dict(pos_x=np.array([1.0]), pos_y=np.array([2.0]), pos_z=np.array([3.0]),
+                              mass=np.array([5.0])))
+    calc.computeForces(d)
+    assert np.all(acc_of(d) == 0)
+    # two bodies, eps = 0 (tests/test_force_calculation.cpp:13-30 on the kernel): a_0 = (1,0,0)
+    d, _ = to_device(nb, dict(pos_x=np.array([0.0, 1.0]), pos_y=np.zeros(2), pos_z=np.zeros(2),
+                              mass=np.ones(2)))
+    calc.setSofteningParameter(0.0)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert abs(a[0, 0] - 1.0) < 1e-5 and abs(a[1, 0] + 1.0) < 1e-5 and np.all(a[:, 1:] == 0)
+    # coincident distinct bodies: contribute nothing (finite), eps = 0 and eps > 0
+    for eps in (0.0, 1e-9, 0.05):
+        ic = nb.ic.sphere(300, seed=1, radius=2.0)
+        for k in ("pos_x", "pos_y", "pos_z"):
+            ic[k][17] = ic[k][5]
+        d, _ = to_device(nb, ic)
+        calc.setSofteningParameter(eps)
+        calc.computeForces(d)
+        a = acc_of(d)
+        assert np.all(np.isfinite(a))
+        keep = np.ones(300, bool)
+        keep[[5, 17]] = False
+        ref = np.stack(oracle.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                            calc.softening_eps2_, 1), 1)
+        if eps > 1e-3:  # with softening the reference's own sum is finite for the pair too
+            assert rel_err(a, ref).max() < TOL
+        else:
+            assert rel_err(a[keep], ref[keep]).max() < TOL
+    # zero-mass bodies feel forces and exert none
+    ic = nb.ic.sphere(513, seed=2, radius=3.0)
+    ic["mass"][::2] = 0.0
+    d, _ = to_device(nb, ic)
+    calc.setSofteningParameter(0.01)
+    calc.computeForces(d)
+    ref = np.stack(oracle.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                        calc.softening_eps2_, 1), 1)
+    assert rel_err(acc_of(d), ref).max() < TOL
+    # ragged sizes around the tile / block boundaries
+    for n in (2, 63, 64, 65, 255, 256, 257, 511, 1025):
+        ic = nb.ic.plummer(n, seed=n)
+        d, _ = to_device(nb, ic)
+        calc.computeForces(d)
+        ref = np.stack(oracle.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                            calc.softening_eps2_, 1), 1)
+        assert rel_err(acc_of(d), ref).max() < TOL, n
+
+
+def test_error_behaviour(nb, ctx):
+    ic = nb.ic.sphere(10, seed=1)
+    d, _ = to_device(nb, ic)
+    for bad in (0, -1, 2048):
+        with pytest.raises(nb.ValidationException):
+            nb.DirectForceCalculator(bad).computeForces(d)
+    with pytest.raises(nb.ValidationException):
+        nb.ParticleDataManager.allocateDevice(nb.ParticleData(), 0)
+    empty = nb.ParticleData()
+    empty.count = 5
+    with pytest.raises(nb.StateException):
+        nb.DirectForceCalculator().computeForces(empty)
+
+
+def test_g_scaling_and_overwrite(nb, ctx):
+    ic = nb.ic.plummer(2000, seed=9)
+    d, _ = to_device(nb, ic)
+    d.acc_x.fill_(123.0)  # computeForces OVERWRITES (force_calculator.hpp:45-58)
+    c1 = nb.DirectForceCalculator()
+    c1.computeForces(d)
+    a1 = acc_of(d)
+    c1.setGravitationalConstant(2.5)
+    c1.computeForces(d)
+    a2 = acc_of(d)
+    assert np.allclose(a2, 2.5 * a1, rtol=3e-7, atol=0)
+
+
+# the sharded (multi-GPU) form: target sub-ranges against all sources, and the
+# local + remote split with `accumulate`
+def test_packed_shards_equal_whole(nb, oracle, ctx):
+    n = 5000
+    ic = nb.ic.plummer(n, seed=11)
+    p = packed(ic)
+    whole = nb.direct_forces_packed(ctx, p, p, 1.0, 1e-6).cpu().numpy()
+    bounds = [0, 700, 1400, 2600, 2601, 4096, n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        part = nb.direct_forces_packed(ctx, p[lo:hi].contiguous(), p, 1.0, 1e-6).cpu().numpy()
+        assert rel_err(part[:, :3], whole[lo:hi, :3]).max() < 2e-6
+        # local pass, then the remote sources accumulated on top
+        t = p[lo:hi].contiguous()
+        acc = nb.direct_forces_packed(ctx, t, t, 1.0, 1e-6)
+        rest = torch.cat([p[:lo], p[hi:]]).contiguous()
+        nb.direct_forces_packed(ctx, t, rest, 1.0, 1e-6, out=acc, accumulate=True)
+        assert rel_err(acc.cpu().numpy()[:, :3], whole[lo:hi, :3]).max() < 2e-6
+    # no sources at all -> zeros
+    z = nb.direct_forces_packed(ctx, p[:10].contiguous(), p[:0].contiguous(), 1.0, 1e-6)
+    assert torch.all(z == 0)
+    # arbitrary target points that are not bodies
+    rng = np.random.default_rng(4)
+    tx, ty, tz = (rng.normal(0, 2, 333).astype(np.float32) for _ in range(3))
+    t = torch.from_numpy(np.stack([tx, ty, tz, np.zeros(333, np.float32)], 1)).cuda()
+    a = nb.direct_forces_packed(ctx, t, p, 1.0, 1e-4).cpu().numpy()
+    ref = np.stack(oracle.direct_forces_points(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"],
+                                               tx, ty, tz, 1.0, 1e-4), 1)
+    assert rel_err(a[:, :3], ref).max() < TOL
+
+
+# BASELINE.json's full size through size-independent properties: Newton's third law
+# (sum m_i a_i = 0), shard consistency and determinism at N = 1,048,576
+def test_full_size_properties(nb, oracle, ctx):
+    n = 1 << 20
+    ic = nb.ic.plummer(n, seed=42)
+    p = packed(ic)
+    eps2 = float(np.float32(1e-3) * np.float32(1e-3))
+    a = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+    b = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+    assert torch.equal(a, b)  # fixed summation order: bitwise reproducible
+    ah = a.cpu().numpy()[:, :3].astype(np.float64)
+    assert np.all(np.isfinite(ah))
+    m = ic["mass"].astype(np.float64)
+    net = np.abs((m[:, None] * ah).sum(0))
+    scale = (m * np.linalg.norm(ah, axis=1)).sum()
+    assert net.max() / scale < 1e-6
+    # rank r of 8 owns targets [r N/8, (r+1) N/8): its shard equals the whole's slice
+    lo, hi = 3 * n // 8, 4 * n // 8
+    part = nb.direct_forces_packed(ctx, p[lo:hi].contiguous(), p, 1.0, eps2).cpu().numpy()
+    assert rel_err(part[:, :3], ah[lo:hi]).max() < 2e-6
+    # and a handful of bodies against the oracle
+    idx = np.array([0, 1, 12345, n // 2, n - 1], dtype=np.int64)
+    ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"],
+                                                idx, 1.0, eps2, 1), 1)
+    assert rel_err(ah[idx], ref).max() < TOL

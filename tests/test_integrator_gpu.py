@@ -1,0 +1,180 @@
+"""Velocity-Verlet and energy kernels (through the C ABI) against the oracle and the
+reference's known answers (tests/test_integrator.cpp, examples/example_energy_conservation.cpp)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import acc_of, rel_err, to_device
+from oracle_bind import host_state
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plummer4096_direct.npz")
+
+
+def _state(d):
+    return {k: getattr(d, k).cpu().numpy().copy() for k in (
+        "pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "acc_x", "acc_y", "acc_z",
+        "acc_old_x", "acc_old_y", "acc_old_z", "mass")}
+
+
+# tests/test_integrator.cpp:15-49
+def test_single_step_position_update(nb, ctx):
+    d, h = to_device(nb, dict(pos_x=np.zeros(1), pos_y=np.zeros(1), pos_z=np.zeros(1),
+                              vel_x=np.ones(1), vel_y=np.zeros(1), vel_z=np.zeros(1),
+                              mass=np.ones(1)))
+    nb.Integrator().updatePositions(d, 0.1)
+    nb.ParticleDataManager.copyToHost(h, d)
+    assert abs(h.pos_x[0] - 0.1) < 1e-5 and abs(h.pos_y[0]) < 1e-5 and abs(h.pos_z[0]) < 1e-5
+
+
+# tests/test_integrator.cpp:51-84
+def test_kinetic_energy_kat(nb, ctx):
+    d, _ = to_device(nb, dict(pos_x=np.zeros(2), pos_y=np.zeros(2), pos_z=np.zeros(2),
+                              vel_x=np.array([1.0, 0.0]), vel_y=np.array([0.0, 2.0]),
+                              vel_z=np.zeros(2), mass=np.array([1.0, 2.0])))
+    assert abs(nb.Integrator().computeKineticEnergy(d) - 4.5) < 1e-4
+
+
+def _binary(nb, r, v):
+    return to_device(nb, dict(pos_x=np.array([-r, r]), pos_y=np.zeros(2), pos_z=np.zeros(2),
+                              vel_x=np.zeros(2), vel_y=np.array([-v, v]), vel_z=np.zeros(2),
+                              mass=np.ones(2)))
+
+
+# tests/test_integrator.cpp:90-162 (see test_oracle_pins.py for why |dE| is compared with |PE|)
+def test_binary_energy_drift(nb, ctx):
+    G, eps, r = 1.0, 0.01, 5.0
+    d, _ = _binary(nb, r, math.sqrt(G * 1.0 / (2 * r)))
+    fc = nb.DirectForceCalculator()
+    fc.setGravitationalConstant(G)
+    fc.setSofteningParameter(eps)
+    integ = nb.Integrator()
+    fc.computeForces(d)
+    e0 = integ.computeTotalEnergy(d, G, eps)
+    for _ in range(100):
+        integ.integrate(d, fc, 0.001)
+    e1 = integ.computeTotalEnergy(d, G, eps)
+    assert abs(integ.computeKineticEnergy(d) - 0.1) < 1e-4
+    assert abs(e1 - e0) < 0.01 * 0.1
+
+
+# examples/example_energy_conservation.cpp:26-147 -- the acceptance program named by north_star
+def test_energy_conservation_example(nb, oracle, ctx):
+    G, eps, dt = 1.0, 0.01, 1e-4
+    d, _ = _binary(nb, 1.0, 0.5)  # accelerations zero at step 0, as in the example (:61-63)
+    fc = nb.DirectForceCalculator()
+    fc.setGravitationalConstant(G)
+    fc.setSofteningParameter(eps)
+    integ = nb.Integrator()
+    e0 = integ.computeKineticEnergy(d) + integ.computePotentialEnergy(d, G, eps)
+    assert abs(e0 - (-0.25)) < 1e-3
+    max_drift = 0.0
+    for _ in range(20):
+        integ.integrate_steps(d, fc, dt, 5000)
+        e = integ.computeKineticEnergy(d) + integ.computePotentialEnergy(d, G, eps)
+        max_drift = max(max_drift, abs((e - e0) / e0) * 100.0)
+    assert max_drift < 0.1  # "excellent" band of the example
+    # same trajectory as the oracle's fp32 restatement, to fp32 round-off growth
+    s = host_state(dict(pos_x=np.array([-1.0, 1.0]), pos_y=np.zeros(2), pos_z=np.zeros(2),
+                        vel_x=np.zeros(2), vel_y=np.array([-0.5, 0.5]), vel_z=np.zeros(2),
+                        mass=np.ones(2)))
+    oracle.integrate_direct(s, G, eps, dt, 100000, 1)
+    g = _state(d)
+    for k in ("pos_x", "pos_y", "vel_x", "vel_y"):
+        assert np.allclose(g[k], s[k], atol=2e-3), k
+
+
+# the three stand-alone kernels against the oracle, ragged N and unaligned views
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1000, 4099])
+def test_vv_kernels_match_oracle(nb, oracle, ctx, n):
+    rng = np.random.default_rng(n)
+    ic = {k: rng.normal(0, 1, n).astype(np.float32) for k in (
+        "pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "acc_x", "acc_y", "acc_z")}
+    ic["mass"] = np.ones(n, np.float32)
+    d, _ = to_device(nb, ic)
+    s = host_state(ic)
+    integ = nb.Integrator()
+    dt = 0.01
+    integ.storeOldAccelerations(d)
+    s["acc_old_x"], s["acc_old_y"], s["acc_old_z"] = s["acc_x"].copy(), s["acc_y"].copy(), s["acc_z"].copy()
+    integ.updatePositions(d, dt)
+    oracle.update_positions(s, dt)
+    d.acc_x.mul_(0.5)
+    s["acc_x"] *= np.float32(0.5)
+    integ.updateVelocities(d, dt)
+    oracle.update_velocities(s, dt)
+    g = _state(d)
+    for k in s:
+        assert np.allclose(g[k], s[k], rtol=3e-7, atol=1e-7), k
+
+
+def test_vv_kernels_unaligned_views(nb, oracle, ctx):
+    n = 1001
+    rng = np.random.default_rng(5)
+    big = {k: torch.from_numpy(rng.normal(0, 1, n + 1).astype(np.float32)).cuda() for k in nb._lib.FIELDS}
+    d = nb.ParticleData()
+    for k in nb._lib.FIELDS:
+        setattr(d, k, big[k][1:])  # 4-byte offset: the scalar path
+    d.count = n
+    s = {k: big[k][1:].cpu().numpy().copy() for k in nb._lib.FIELDS}
+    nb.Integrator().updatePositions(d, 0.02)
+    oracle.update_positions(s, 0.02)
+    nb.Integrator().updateVelocities(d, 0.02)
+    oracle.update_velocities(s, 0.02)
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert np.allclose(getattr(d, k).cpu().numpy(), s[k], rtol=3e-7, atol=1e-7), k
+        assert big[k][0].item() == pytest.approx(float(big[k][0]))  # neighbour untouched
+
+
+# Integrator::integrate: fused path == the reference's 4-call sequence == oracle
+def test_integrate_fused_equals_sequence_and_golden(nb, oracle, ctx):
+    g = np.load(GOLD)
+    ic = {k: g[k] for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
+    G, eps, dt = float(g["G"]), float(g["eps"]), float(g["dt"])
+    fc = nb.DirectForceCalculator()
+    fc.setGravitationalConstant(G)
+    fc.setSofteningParameter(eps)
+    integ = nb.Integrator()
+    d1, _ = to_device(nb, ic)
+    d2, _ = to_device(nb, ic)
+    fc.computeForces(d1)   # ParticleSystem::initialize does this once (particle_system.cpp:88-91)
+    fc.computeForces(d2)
+    for _ in range(10):
+        integ.integrate(d1, fc, dt)                      # fused
+        integ.storeOldAccelerations(d2)                  # integrator.cu:224-238 spelled out
+        integ.updatePositions(d2, dt)
+        fc.computeForces(d2)
+        integ.updateVelocities(d2, dt)
+    s1, s2 = _state(d1), _state(d2)
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert np.allclose(s1[k], s2[k], rtol=1e-6, atol=1e-7), k
+        assert np.allclose(s1[k], g["step10_" + k], rtol=2e-5, atol=2e-6), k
+    a = np.stack([s1["acc_x"], s1["acc_y"], s1["acc_z"]], 1)
+    ref = np.stack([g["step10_acc_x"], g["step10_acc_y"], g["step10_acc_z"]], 1)
+    assert np.median(rel_err(a, ref)) < 1e-5
+
+
+def test_energies_match_oracle(nb, oracle, ctx):
+    g = np.load(GOLD)
+    ic = {k: g[k] for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
+    d, _ = to_device(nb, ic)
+    integ = nb.Integrator()
+    ke, pe = integ.computeEnergiesF64(d, 1.0, float(g["eps"]))
+    assert abs(ke - float(g["ke"])) / float(g["ke"]) < 1e-6
+    assert abs(pe - float(g["pe"])) / abs(float(g["pe"])) < 1e-6
+    # virial sanity of the Plummer model: 2 KE / |PE| ~ 1
+    assert 0.9 < 2 * ke / abs(pe) < 1.1
+    # float API == rounded fp64 value, total = fp32 sum (integrator.cu:291-293)
+    assert integ.computeKineticEnergy(d) == np.float32(ke)
+    assert integ.computePotentialEnergy(d, 1.0, float(g["eps"])) == np.float32(pe)
+    # a larger, ragged case against the fp64 oracle
+    ic = nb.ic.plummer(20001, seed=8)
+    d, _ = to_device(nb, ic)
+    s = host_state(ic)
+    ke, pe = integ.computeEnergiesF64(d, 1.5, 0.01)
+    assert abs(ke - oracle.kinetic_energy(s, 256, 2)) / ke < 1e-6
+    ref = oracle.potential_energy(s, 1.5, 0.01, 256, 2)
+    assert abs(pe - ref) / abs(ref) < 1e-6

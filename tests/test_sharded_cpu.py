@@ -1,0 +1,118 @@
+"""The N>1 path (index-range shards + per-step all-gather + local/remote split) on CPU tensors
+with the gloo backend, world_size 2 and 3.  The force math is injected from the oracle here (the
+product backend is HIP-only); what is under test is the partition / collective / buffer-swap
+logic of n-body_amd/distributed.py, which is identical on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """CPU stand-in for HipBackend, built on the oracle's restated arithmetic (tests only)."""
+
+    def __init__(self):
+        import oracle_bind
+        self.o = oracle_bind.load()
+        self.device = torch.device("cpu")
+
+    def drift(self, posm, vel, acc, dt):
+        p, v, a = posm.numpy(), vel.numpy(), acc.numpy()
+        dt = np.float32(dt)
+        h = np.float32(0.5) * dt * dt
+        p[:, :3] += v[:, :3] * dt + a[:, :3] * h
+
+    def kick(self, vel, acc_old, acc_new, dt):
+        v = vel.numpy()
+        v[:, :3] += (acc_old.numpy()[:, :3] + acc_new.numpy()[:, :3]) * (np.float32(0.5) * np.float32(dt))
+
+    def forces(self, targets, sources, G, eps2, out, accumulate):
+        t, s = targets.numpy(), sources.numpy()
+        c = np.ascontiguousarray
+        if s.shape[0] == 0:
+            a = np.zeros((t.shape[0], 3), np.float32)
+        else:
+            a = np.stack(self.o.direct_forces_points(c(s[:, 0]), c(s[:, 1]), c(s[:, 2]), c(s[:, 3]),
+                                                     c(t[:, 0]), c(t[:, 1]), c(t[:, 2]), G, eps2), 1)
+        o = out.numpy()
+        if accumulate:
+            o[:, :3] += a
+        else:
+            o[:, :3] = a
+            o[:, 3] = 0
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nbody_amd
+        from nbody_amd.distributed import ShardedDirectSystem, shard_bounds
+        ic = nbody_amd.ic.plummer(n, seed=5)
+        sysm = ShardedDirectSystem(ic, 1.0, 0.01, backend=OracleBackend(), device="cpu")
+        S, lo, hi = shard_bounds(n, world, rank)
+        assert (sysm.S, sysm.lo, sysm.hi) == (S, lo, hi)
+        sysm.initial_forces()
+        for _ in range(steps):
+            sysm.step(1e-3)
+        pos = sysm.gather_global("posm")
+        vel = sysm.gather_global("vel")
+        acc = sysm.gather_global("acc")
+        ke = sysm.kinetic_energy()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"w{world}.npz"), pos=pos, vel=vel, acc=acc, ke=ke)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 600), (3, 601)])
+def test_sharded_steps_match_single_process(tmp_path, world, n, oracle, nb):
+    from oracle_bind import host_state
+    steps = 3
+    mp.spawn(_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / f"w{world}.npz")
+    ic = nb.ic.plummer(n, seed=5)
+    s = host_state(ic)
+    eps2 = float(np.float32(0.01) * np.float32(0.01))
+    s["acc_x"], s["acc_y"], s["acc_z"] = oracle.direct_forces(s["pos_x"], s["pos_y"], s["pos_z"],
+                                                              s["mass"], 1.0, eps2, 1)
+    oracle.integrate_direct(s, 1.0, 0.01, 1e-3, steps, 1)
+    for k, col in (("pos_x", 0), ("pos_y", 1), ("pos_z", 2)):
+        assert np.allclose(got["pos"][:, col], s[k], rtol=1e-6, atol=1e-6), k
+    assert np.array_equal(got["pos"][:, 3], s["mass"])
+    for k, col in (("vel_x", 0), ("vel_y", 1), ("vel_z", 2)):
+        assert np.allclose(got["vel"][:, col], s[k], rtol=1e-5, atol=1e-6), k
+    for k, col in (("acc_x", 0), ("acc_y", 1), ("acc_z", 2)):
+        assert np.allclose(got["acc"][:, col], s[k], rtol=2e-5, atol=1e-6), k
+    assert abs(float(got["ke"]) - oracle.kinetic_energy(s, 256, 2)) < 1e-6
+
+
+def test_shard_bounds(nb):
+    from nbody_amd.distributed import shard_bounds
+    for n, w in ((1 << 20, 8), (10, 3), (7, 8), (1, 1)):
+        sizes, prev_hi = [], 0
+        for r in range(w):
+            S, lo, hi = shard_bounds(n, w, r)
+            assert lo == min(n, prev_hi) or lo == prev_hi
+            assert hi - lo <= S
+            sizes.append(hi - lo)
+            prev_hi = hi
+        assert sum(sizes) == n
+    assert shard_bounds(1 << 20, 8, 3) == (131072, 393216, 524288)
