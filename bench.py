@@ -127,7 +127,7 @@ def main():
 
     ctx = nb.default_context(local_rank)
     if a.variant >= 0 or a.tpl or a.splits:
-        ctx.tuning(max(a.variant, 0), a.tpl, a.splits)
+        ctx.tuning(a.variant, a.tpl, a.splits)
 
     n = a.n
     ic = nb.ic.plummer(n, seed=42)  # every rank builds the same bodies, keeps its shard

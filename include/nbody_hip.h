@@ -83,12 +83,12 @@ NBODY_HIP_API const char* nbody_hip_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU; never fails). */
 NBODY_HIP_API int nbody_hip_device_count(void);
 
-/* Creates a context on `device`.  `stream` is a hipStream_t the caller owns, or
- * NULL to let the context create (and own) a non-blocking stream.
- * ref: the reference uses device 0 / the null stream implicitly (force_direct.cu:93). */
+/* Creates a context on `device`.  `stream` is a hipStream_t the caller owns; NULL means HIP's
+ * default (null) stream, which is what the reference launches on (force_direct.cu:93).  The
+ * context never creates streams of its own. */
 NBODY_HIP_API int nbody_hip_ctx_create(nbody_hip_ctx** out, int device, void* stream);
 NBODY_HIP_API int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx);
-/* Re-targets later launches to another caller-owned stream (NULL = the context's own). */
+/* Re-targets later launches to another caller-owned stream (NULL = the null stream). */
 NBODY_HIP_API int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream);
 /* Blocks until all work queued on the context's stream is done.
  * ref: CUDA_CHECK_KERNEL's debug-mode cudaDeviceSynchronize, error_handling.hpp:124-136 */
@@ -179,7 +179,8 @@ NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_f
                                  nbody_float4* acc_out, float G, float eps2, int iters,
                                  float* ms_per_launch);
 
-/* Tuning knobs for experiments (0 = automatic).  variant: kernel body variant id;
+/* Tuning knobs for experiments.  variant: -1 automatic, 0 scalar body + LDS sources, 1 packed
+ * (v_pk_*_f32) body + LDS sources, 2 scalar body + scalar-cache sources; the others 0 = automatic:
  * targets_per_lane: 1, 2 or 4; source_splits: number of source sub-ranges per target block. */
 NBODY_HIP_API int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
                             int source_splits);

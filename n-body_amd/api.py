@@ -137,7 +137,7 @@ class Context:
     def synchronize(self):
         check(self._lib.nbody_hip_ctx_synchronize(self._h))
 
-    def tuning(self, variant=0, targets_per_lane=0, source_splits=0):
+    def tuning(self, variant=-1, targets_per_lane=0, source_splits=0):
         check(self._lib.nbody_hip_direct_tuning(self._h, variant, targets_per_lane, source_splits))
 
     def close(self):

@@ -80,16 +80,9 @@ extern "C" int nbody_hip_ctx_create(nbody_hip_ctx** out, int device, void* strea
   NBH_HIP(hipSetDevice(device));
   nbody_hip_ctx* c = new nbody_hip_ctx();
   c->device = device;
-  if (stream) {
-    c->stream = static_cast<hipStream_t>(stream);
-  } else {
-    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      delete c;
-      return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
-    }
-    c->stream = c->own_stream;
-  }
+  // NULL = HIP's default (null) stream, which is what the reference launches on
+  // (force_direct.cu:93) and what torch.cuda.current_stream() is unless a side stream is active.
+  c->stream = static_cast<hipStream_t>(stream);
   hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->host_scalar), 4 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -104,29 +97,20 @@ extern "C" int nbody_hip_ctx_create(nbody_hip_ctx** out, int device, void* strea
 extern "C" int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx) {
   if (!ctx) return NBODY_HIP_OK;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   ctx->posm.release();
   ctx->partial.release();
   ctx->reduce.release();
   if (ctx->host_scalar) (void)hipHostFree(ctx->host_scalar);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return NBODY_HIP_OK;
 }
 
 extern "C" int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
-  if (stream) {
-    ctx->stream = static_cast<hipStream_t>(stream);
-  } else {
-    if (!ctx->own_stream) {
-      NBH_HIP(hipSetDevice(ctx->device));
-      NBH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    }
-    ctx->stream = ctx->own_stream;
-  }
+  ctx->stream = static_cast<hipStream_t>(stream);
   return NBODY_HIP_OK;
 }
 
@@ -302,7 +286,7 @@ extern "C" int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_floa
 extern "C" int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
                                        int source_splits) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
-  if (variant < 0 || variant > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "variant must be 0, 1 or 2");
+  if (variant < -1 || variant > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "variant must be -1 (auto), 0, 1 or 2");
   if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "targets_per_lane must be 0 (auto), 1, 2 or 4");
   if (source_splits < 0 || source_splits > 4096)

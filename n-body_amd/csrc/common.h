@@ -48,15 +48,14 @@ struct Workspace {
 
 struct nbody_hip_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;      // stream launches go to
-  hipStream_t own_stream = nullptr;  // created by the context (may be null)
+  hipStream_t stream = nullptr;      // caller-owned stream launches go to (nullptr = null stream)
   nbh::Workspace posm;               // packed {x,y,z,m} of the bodies        (direct, energy)
   nbh::Workspace partial;            // per-source-split partial accelerations (direct)
   nbh::Workspace reduce;             // block partials for energy reductions
   double* host_scalar = nullptr;     // pinned, 4 doubles
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // tuning overrides (0 = automatic)
-  int tune_variant = 0, tune_tpl = 0, tune_splits = 0;
+  // tuning overrides (variant -1 / others 0 = automatic)
+  int tune_variant = -1, tune_tpl = 0, tune_splits = 0;
 };
 
 namespace nbh {

@@ -247,15 +247,17 @@ static Shape choose_shape(const nbody_hip_ctx* ctx, size_t n_tgt, size_t n_src) 
   Shape s;
   // Targets per lane: 4 once every CU still gets >= 4 blocks; small problems prefer more
   // blocks over more ILP.
-  int R = 2;
-  if (n_tgt >= (size_t)kBlock * 4 * kNumCU * 4) R = 4;
+  // Measured on MI355X (tools/sweep_direct.py): 4 targets per lane wins from N = 2.6e5 up;
+  // below ~3e4 targets more blocks matter more than ILP.
+  int R = n_tgt >= 32768 ? 4 : 2;
   if (ctx->tune_tpl == 1 || ctx->tune_tpl == 2 || ctx->tune_tpl == 4) R = ctx->tune_tpl;
   s.R = R;
   s.blocks_x = (int)((n_tgt + (size_t)kBlock * R - 1) / ((size_t)kBlock * R));
   s.n_tgt_pad = s.blocks_x * kBlock * R;
   const int tiles = (int)((n_src + TS - 1) / TS);
-  // Aim for >= 8 blocks per CU in flight/queued so the tail is short.
-  int want = (kNumCU * 8 + s.blocks_x - 1) / s.blocks_x;
+  // Aim for >= 16 blocks per CU queued so the last wave of blocks is short (measured: 4096
+  // blocks beat 1024/2048 at N = 2^20 by 3-7 %).
+  int want = (kNumCU * 16 + s.blocks_x - 1) / s.blocks_x;
   if (want < 1) want = 1;
   if (want > 64) want = 64;
   if (ctx->tune_splits > 0) want = ctx->tune_splits;
@@ -291,8 +293,9 @@ int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
 
   // m * rsq(eps2)^3 must stay finite for the branch-free self-pair trick.
   const bool guard = eps2 < 1e-12f;
+  // automatic choice: the packed body (measured 4.2e12 vs 3.5e12 pairs/s for the scalar body)
   int variant = ctx->tune_variant;
-  if (variant < 0 || variant > 2) variant = 0;
+  if (variant < 0 || variant > 2) variant = s.R >= 2 ? 1 : 0;
   if (guard && variant == 1) variant = 0;
   const int nt = (int)n_targets, ns = (int)n_sources;
 

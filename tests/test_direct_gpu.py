@@ -66,7 +66,7 @@ def test_variants_agree_with_oracle(nb, oracle, ctx, variant, tpl, splits):
         a = nb.direct_forces_packed(ctx, p, p, 1.0, 1e-6)
         torch.cuda.synchronize()
     finally:
-        ctx.tuning(0, 0, 0)
+        ctx.tuning()
     a = a.cpu().numpy()
     assert np.all(a[:, 3] == 0)
     assert rel_err(a[:, :3], ref).max() < TOL
