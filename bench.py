@@ -55,6 +55,26 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_share():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(ic, eps, seconds):
     """Times the oracle (kind "port": the reference has no CPU force path) on a
     bounded sample: T targets spread over the index range x all N sources, fp32 sequential sum."""
@@ -74,7 +94,8 @@ def cpu_baseline(ic, eps, seconds):
         lib = oracle_bind.load(fast=True)
     n = ic["pos_x"].size
     eps2 = float(np.float32(eps) * np.float32(eps))
-    cores = lib.num_threads()
+    cores = min(lib.num_threads(), cpu_share())
+    lib.L.oracle_set_num_threads(cores)
     x, y, z, m = ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"]
 
     def run(t):
@@ -85,6 +106,9 @@ def cpu_baseline(ic, eps, seconds):
 
     t_probe = max(cores * 4, 32)
     dt = run(t_probe)
+    while dt < 0.5 and t_probe < n // 8:  # probe long enough to see the steady rate
+        t_probe *= 4
+        dt = run(t_probe)
     rate = t_probe * n / dt
     targets = int(min(n, max(t_probe, rate * seconds / n)))
     targets = max(cores, targets // cores * cores)
