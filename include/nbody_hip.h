@@ -169,6 +169,36 @@ NBODY_HIP_API int nbody_hip_kinetic_energy_f64(nbody_hip_ctx* ctx, const nbody_p
 NBODY_HIP_API int nbody_hip_potential_energy_f64(nbody_hip_ctx* ctx, const nbody_particle_data* d, float G,
                                    float eps, double* out);
 
+/* ---- a9: spatial hash (ref: SpatialHashGrid / SpatialHashCalculator,
+ *          src/cuda/force_spatial_hash.cu:14-377, include/nbody/spatial_hash_grid.hpp:9-59) ---- */
+
+typedef struct nbody_hip_grid nbody_hip_grid;
+
+/* ref: SpatialHashGrid(max_particles, cell_size) :155-168.  Sized once from `max_particles`
+ * (the reference sizes its grid from the first count it sees, :372-374). */
+NBODY_HIP_API int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, float cell_size,
+                                        nbody_hip_grid** out);
+NBODY_HIP_API int nbody_hip_grid_destroy(nbody_hip_grid* grid);
+/* ref: SpatialHashCalculator::setCellSize (force_calculator.hpp:199): takes effect at the next build */
+NBODY_HIP_API int nbody_hip_grid_set_cell_size(nbody_hip_grid* grid, float cell_size);
+/* ref: SpatialHashGrid::build :235-303 -- bounding box (padded 0.001), grid dims
+ * ceil(extent/cell)+1, cell id per body, bodies ordered by cell.  More than 1e8 cells ->
+ * NBODY_HIP_ERR_RESOURCE ("Spatial hash grid too large", :252-254).  One host round trip
+ * (the grid size), like the reference. */
+NBODY_HIP_API int nbody_hip_grid_build(nbody_hip_grid* grid, const nbody_particle_data* d);
+/* ref: SpatialHashGrid::computeForces(d_particles, cutoff, G, eps) :305-316 -- takes eps and
+ * cutoff unsquared like the reference; OVERWRITES acc_*. */
+NBODY_HIP_API int nbody_hip_grid_compute_forces(nbody_hip_grid* grid, nbody_particle_data* d,
+                                                float cutoff, float G, float eps);
+/* ref: getGridDims / getTotalCells (spatial_hash_grid.hpp:20-24) + the padded bounding box. */
+NBODY_HIP_API int nbody_hip_grid_info(const nbody_hip_grid* grid, int dims[3], int* total_cells,
+                                      float bbox_min[3], float bbox_max[3]);
+/* ref: copyCellDataToHost :318-331 -- HOST output arrays (any may be NULL): cell_start/cell_end
+ * [total_cells] (0/0 for an empty cell), particle_cells [count], sorted_indices [count].
+ * Blocking. */
+NBODY_HIP_API int nbody_hip_grid_copy_cell_data(nbody_hip_grid* grid, int* cell_start, int* cell_end,
+                                                int* particle_cells, int* sorted_indices);
+
 /* ---- measurement helpers -------------------------------------------------- */
 
 /* Runs the direct-force kernel `iters` times back to back on the context's stream between

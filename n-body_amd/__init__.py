@@ -10,5 +10,6 @@ from ._lib import (DeviceException, NBodyError, ResourceException, StateExceptio
 from .api import *  # noqa: F401,F403
 from .api import (Context, DirectForceCalculator, ForceCalculator, ForceMethod,  # noqa: F401
                   InitDistribution, Integrator, ParticleData, ParticleDataManager,
-                  SimulationConfig, createForceCalculator, default_context,
+                  SimulationConfig, SpatialHashCalculator, SpatialHashGrid,
+                  createForceCalculator, default_context,
                   direct_forces_packed, pack_posm, time_direct_packed)

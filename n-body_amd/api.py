@@ -306,11 +306,143 @@ class DirectForceCalculator(ForceCalculator):
         return self.block_size_
 
 
+class SpatialHashGrid:
+    """spatial_hash_grid.hpp:9-59 / force_spatial_hash.cu:155-361."""
+
+    def __init__(self, max_particles: int, cell_size: float = 1.0, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.max_particles_ = int(max_particles)
+        self.cell_size_ = float(cell_size)
+        h = C.c_void_p()
+        check(self.ctx._lib.nbody_hip_grid_create(self.ctx.handle, self.max_particles_,
+                                                  self.cell_size_, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.ctx._lib.nbody_hip_grid_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def setCellSize(self, size):
+        check(self.ctx._lib.nbody_hip_grid_set_cell_size(self._h, size))
+        self.cell_size_ = float(size)
+
+    def build(self, d_particles: ParticleData):
+        s = d_particles.struct()
+        self._last_count = d_particles.count
+        check(self.ctx._lib.nbody_hip_grid_build(self._h, C.byref(s)))
+
+    def computeForces(self, d_particles: ParticleData, cutoff: float, G: float, eps: float):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_grid_compute_forces(self._h, C.byref(s), cutoff, G, eps))
+
+    def _info(self):
+        dims, total = (C.c_int * 3)(), C.c_int()
+        lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
+        check(self.ctx._lib.nbody_hip_grid_info(self._h, C.byref(dims), C.byref(total),
+                                                C.byref(lo), C.byref(hi)))
+        return list(dims), total.value, list(lo), list(hi)
+
+    def getGridDims(self):
+        return tuple(self._info()[0])
+
+    def getCellSize(self):
+        return self.cell_size_
+
+    def getTotalCells(self):
+        return self._info()[1]
+
+    def getBoundingBox(self):
+        _, _, lo, hi = self._info()
+        return lo, hi
+
+    def copyCellDataToHost(self):
+        """-> (cell_start, cell_end, particle_cells, sorted_indices) as numpy int32 arrays."""
+        dims, total, _, _ = self._info()
+        n = self._count()
+        cs, ce = np.empty(total, np.int32), np.empty(total, np.int32)
+        pc, si = np.empty(n, np.int32), np.empty(n, np.int32)
+        check(self.ctx._lib.nbody_hip_grid_copy_cell_data(self._h, cs.ctypes.data, ce.ctypes.data,
+                                                          pc.ctypes.data, si.ctypes.data))
+        return cs, ce, pc, si
+
+    def _count(self):
+        return self._last_count
+
+    @staticmethod
+    def getCellIndex(x, y, z, cell_size):
+        """force_spatial_hash.cu:14-17: floor of each coordinate over the cell size (fp32)."""
+        f = np.float32
+        return tuple(int(np.floor(f(v) / f(cell_size))) for v in (x, y, z))
+
+    def verifyCellAssignment(self, h_particles: ParticleData) -> bool:
+        """force_spatial_hash.cu:333-362: every body lies inside the bounds of its (clamped) cell."""
+        dims, _, lo, _ = self._info()
+        _, _, pc, _ = self.copyCellDataToHost()
+        cs = np.float32(self.cell_size_)
+        cell = np.stack([pc % dims[0], (pc // dims[0]) % dims[1], pc // (dims[0] * dims[1])], 1)
+        for a, f in enumerate(("pos_x", "pos_y", "pos_z")):
+            p = getattr(h_particles, f)[: pc.size]
+            exp = np.clip(np.floor((p - np.float32(lo[a])) / cs).astype(np.int64), 0, dims[a] - 1)
+            if not np.array_equal(exp, cell[:, a]):
+                return False
+            cmin = np.float32(lo[a]) + cell[:, a].astype(np.float32) * cs
+            if np.any(p < cmin) or np.any(p > cmin + cs):
+                return False
+        return True
+
+
+class SpatialHashCalculator(ForceCalculator):
+    """force_calculator.hpp:176-211 / force_spatial_hash.cu:364-377: the grid is created lazily at
+    the first computeForces and sized from that particle count."""
+
+    def __init__(self, cell_size: float = 1.0, cutoff_radius: float = 2.0, ctx: Context | None = None):
+        super().__init__(ctx)
+        self.grid_ = None
+        self.cell_size_ = float(cell_size)
+        self.cutoff_radius_ = float(cutoff_radius)
+
+    def computeForces(self, d_particles: ParticleData):
+        if self.grid_ is None:
+            self.grid_ = SpatialHashGrid(d_particles.count, self.cell_size_, self.ctx)
+        self.grid_._last_count = d_particles.count
+        self.grid_.build(d_particles)
+        self.grid_.computeForces(d_particles, self.cutoff_radius_, self.G_, self.softening_eps_)
+
+    def getMethod(self):
+        return ForceMethod.SPATIAL_HASH
+
+    def setCellSize(self, size):
+        self.cell_size_ = float(size)
+        if self.grid_ is not None:
+            self.grid_.setCellSize(size)
+
+    def setCutoffRadius(self, radius):
+        self.cutoff_radius_ = float(radius)
+
+    def getCellSize(self):
+        return self.cell_size_
+
+    def getCutoffRadius(self):
+        return self.cutoff_radius_
+
+    def getGrid(self):
+        return self.grid_
+
+
 def createForceCalculator(method: ForceMethod, config: SimulationConfig,
                           ctx: Context | None = None) -> ForceCalculator:
     """force_spatial_hash.cu:380-401: unknown enumerators fall back to Direct."""
-    if method == ForceMethod.BARNES_HUT or method == ForceMethod.SPATIAL_HASH:
-        raise NotImplementedError(f"{ForceMethod(method).name} is not built yet in this tree")
+    if method == ForceMethod.BARNES_HUT:
+        raise NotImplementedError("BARNES_HUT is not built yet in this tree")
+    if method == ForceMethod.SPATIAL_HASH:
+        calc = SpatialHashCalculator(config.spatial_hash_cell_size, config.spatial_hash_cutoff, ctx)
+        calc.setGravitationalConstant(config.G)
+        calc.setSofteningParameter(config.softening)
+        return calc
     calc = DirectForceCalculator(config.cuda_block_size, ctx)
     calc.setGravitationalConstant(config.G)
     calc.setSofteningParameter(config.softening)

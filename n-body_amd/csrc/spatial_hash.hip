@@ -1,0 +1,484 @@
+// spatial_hash.hip -- short-range forces on a uniform cell grid, gfx950.
+//
+// Replaces SpatialHashGrid / SpatialHashCalculator of the reference
+// (src/cuda/force_spatial_hash.cu:14-377).  Same semantics:
+//   * grid = bounding box padded by 0.001, dims = ceil(extent/cell)+1 (:225-231, :244-246),
+//     > 1e8 cells is an error (:252-254); cell id = x + y gx + z gx gy of floor((p-min)/cell),
+//     clamped (:36-48);
+//   * a body interacts with the bodies of its own and the 26 adjacent cells that exist
+//     (non-periodic, :104-113) whose UNSOFTENED distance^2 is below cutoff^2 (:131-135);
+//     softening is added after the test; the body itself is skipped (:124).
+// Different machine mapping:
+//   * binning is a stable LSD radix sort of (cell id, body index) (rocPRIM, AMD's native device
+//     primitives) instead of atomic count / Thrust scan / atomic scatter (:52-80), so the
+//     within-cell order is the body-index order and results are bitwise reproducible (the
+//     reference's scatter order is non-deterministic);
+//   * bodies are physically reordered into float4 {x,y,z,m} in cell order, so every cell -- and
+//     every run of cells along x -- is one contiguous, coalesced range (the reference gathers
+//     pos[sorted_indices[k]] per pair, :123-129);
+//   * force kernel: one workgroup per RUN of W cells along x.  Its targets are one contiguous
+//     range; its sources are the 9 rows (y+-1, z+-1) x cells [x0-1, x0+W], i.e. NINE contiguous
+//     ranges, streamed through LDS tiles and broadcast to the waves exactly like the Direct
+//     kernel.  Range ends come from binary searches in the sorted key array (no per-cell
+//     start/end arrays on the force path).  When cutoff > cell_size the reference's 27-cell
+//     search misses pairs; the STRICT variant reproduces that by testing |cx_j - cx_i| <= 1.
+//
+// Roofline: the build is HBM/sort bound (~48 B/body), the force kernel is VALU bound at
+// ~9 (W+2)/W rho candidate pairs per body (rho = bodies per cell), fed from L2/LDS.
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace nbh {
+
+constexpr int HTS = 256;  // sources per LDS tile
+
+__device__ __forceinline__ unsigned int float_to_ordered(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(unsigned int o) {
+  const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+__global__ void bbox_init_kernel(unsigned int* enc) {
+  if (threadIdx.x < 3) enc[threadIdx.x] = 0xffffffffu;      // mins
+  else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;           // maxs
+}
+
+// min/max of x,y,z: wave64 shuffle reduce, one atomic per wave on order-preserving integers
+// (the reference CAS-loops float atomics from every block, force_barnes_hut.cu:41-110)
+__global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__ posm, int n,
+                                                      unsigned int* __restrict__ enc) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = posm[i];
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&enc[a], float_to_ordered(lo[a]));
+      atomicMax(&enc[3 + a], float_to_ordered(hi[a]));
+    }
+  }
+}
+
+struct GridInfo {
+  float bmin[3];
+  float bmax[3];
+  int dims[3];
+  int pad;
+  long long total;
+};
+
+// decode, pad by `pad` (0.001 for the hash grid, force_spatial_hash.cu:225-231), size the grid
+__global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cell, float pad,
+                                 GridInfo* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  long long total = 1;
+  for (int a = 0; a < 3; a++) {
+    const float lo = ordered_to_float(enc[a]) - pad;
+    const float hi = ordered_to_float(enc[3 + a]) + pad;
+    info->bmin[a] = lo;
+    info->bmax[a] = hi;
+    const float cells = ceilf((hi - lo) / cell);
+    // guard the int conversion: anything beyond 2^30 is reported as "too large" by the host
+    const int d = (cells < 1.0e9f && cells >= 0.0f) ? (int)cells + 1 : 0x40000000;
+    info->dims[a] = d;
+    total *= d;
+    if (total > 0x4000000000000LL) total = 0x4000000000000LL;
+  }
+  info->total = total;
+}
+
+__device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim) {
+  int c = (int)floorf((p - lo) / cell);
+  return min(max(c, 0), dim - 1);
+}
+
+// force_spatial_hash.cu:28-49
+__global__ __launch_bounds__(kBlock) void assign_cells_kernel(const float4* __restrict__ posm, int n,
+                                                              const GridInfo* __restrict__ info,
+                                                              float cell,
+                                                              unsigned int* __restrict__ keys,
+                                                              int* __restrict__ idx) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i];
+  const int gx = info->dims[0], gy = info->dims[1], gz = info->dims[2];
+  const int cx = cell_coord(p.x, info->bmin[0], cell, gx);
+  const int cy = cell_coord(p.y, info->bmin[1], cell, gy);
+  const int cz = cell_coord(p.z, info->bmin[2], cell, gz);
+  keys[i] = (unsigned int)(cx + cy * gx + cz * gx * gy);
+  idx[i] = i;
+}
+
+// physical reorder into cell order
+__global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const float4* __restrict__ posm,
+                                                               const int* __restrict__ idx, int n,
+                                                               float4* __restrict__ out) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < n) out[k] = posm[idx[k]];
+}
+
+// per-cell [start, end) for the inspection API (copyCellDataToHost); empty cells stay 0/0
+__global__ __launch_bounds__(kBlock) void cell_ranges_kernel(const unsigned int* __restrict__ keys,
+                                                             int n, int* __restrict__ cell_start,
+                                                             int* __restrict__ cell_end) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const unsigned int c = keys[k];
+  if (k == 0 || keys[k - 1] != c) cell_start[c] = k;
+  if (k == n - 1 || keys[k + 1] != c) cell_end[c] = k + 1;
+}
+
+__device__ __forceinline__ int lower_bound_keys(const unsigned int* __restrict__ keys, int n,
+                                                unsigned int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------------------
+// Force kernel.  grid = (ceil(gx / W), gy, gz); block = 256.
+// GUARD : eps2 so small that m*rsq(eps2)^3 may overflow -> d2 > 0 tested explicitly
+// STRICT: cutoff > cell_size -> only x-adjacent cells interact (the reference's 27-cell search)
+// ---------------------------------------------------------------------------------------
+template <bool GUARD, bool STRICT>
+__global__ __launch_bounds__(kBlock) void hash_force_kernel(
+    const float4* __restrict__ sorted, const unsigned int* __restrict__ keys,
+    const int* __restrict__ idx, int n, const GridInfo* __restrict__ info, int W, float cutoff2,
+    float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
+    float* __restrict__ acc_z) {
+  __shared__ int range[20];  // [0,1] targets; [2+2r, 3+2r] source row r (0..8)
+  __shared__ float4 tile[2][HTS];
+  __shared__ int tile_cx[2][HTS];
+  const int tid = threadIdx.x;
+  const int gx = info->dims[0], gy = info->dims[1], gz = info->dims[2];
+  const int x0 = blockIdx.x * W, y = blockIdx.y, z = blockIdx.z;
+  const int x1 = min(x0 + W, gx);
+
+  if (tid < 20) {
+    int r = -1;  // -1: targets
+    int which = tid & 1;
+    if (tid >= 2) r = (tid - 2) >> 1;
+    int val = 0;
+    if (r < 0) {
+      const unsigned int base = (unsigned int)((z * gy + y) * gx);
+      val = lower_bound_keys(keys, n, base + (unsigned int)(which ? x1 : x0));
+    } else {
+      const int yy = y + (r % 3) - 1, zz = z + (r / 3) - 1;
+      if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+        const unsigned int base = (unsigned int)((zz * gy + yy) * gx);
+        const int xa = max(x0 - 1, 0), xb = min(x1 + 1, gx);
+        val = lower_bound_keys(keys, n, base + (unsigned int)(which ? xb : xa));
+      }
+    }
+    range[tid] = val;
+  }
+  __syncthreads();
+  const int t0 = range[0], t1 = range[1];
+  if (t0 >= t1) return;  // empty run (uniform over the block)
+
+  int tc = 0;  // running tile counter: buffer = tc & 1, ONE barrier per tile (the other buffer is
+               // only rewritten after the next barrier, when every wave has left it)
+  for (int tb = t0; tb < t1; tb += kBlock) {
+    const int t = tb + tid;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cxi = 0;
+    if (t < t1) {
+      pi = sorted[t];
+      if (STRICT) cxi = (int)(keys[t] % (unsigned int)gx);
+    }
+    // fp32 sums of 64 sources folded into fp64: a dense cell neighbourhood is thousands of terms
+    // with heavy cancellation (uniform interior); long fp32 running sums would cost digits
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int r = 0; r < 9; r++) {
+      const int s0 = range[2 + 2 * r], s1 = range[3 + 2 * r];
+      for (int jb = s0; jb < s1; jb += HTS, tc++) {
+        const int b = tc & 1;
+        const int j = jb + tid;
+        if (j < s1) {
+          tile[b][tid] = sorted[j];
+          if (STRICT) tile_cx[b][tid] = (int)(keys[j] % (unsigned int)gx);
+        }
+        __syncthreads();
+        const int cnt = min(HTS, s1 - jb);
+        for (int kb = 0; kb < cnt; kb += 64) {  // fold every 64 sources: see comment above
+          float ax = 0.f, ay = 0.f, az = 0.f;
+          const int ke = min(kb + 64, cnt);
+#pragma unroll 4
+          for (int k = kb; k < ke; k++) {
+            const float4 s = tile[b][k];
+            const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
+            const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+            const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+            bool ok = d2 < cutoff2;                       // :131, unsoftened distance
+            if (GUARD) ok = ok && (d2 > 0.f);             // coincident / self: contributes 0
+            if (STRICT) ok = ok && (abs(tile_cx[b][k] - cxi) <= 1);
+            const float f = ok ? (s.w * inv) * (inv * inv) : 0.f;
+            ax = __builtin_fmaf(f, dx, ax);
+            ay = __builtin_fmaf(f, dy, ay);
+            az = __builtin_fmaf(f, dz, az);
+          }
+          sx += (double)ax; sy += (double)ay; sz += (double)az;
+        }
+      }
+    }
+    if (t < t1) {
+      const int i = idx[t];
+      acc_x[i] = (float)((double)G * sx);
+      acc_y[i] = (float)((double)G * sy);
+      acc_z[i] = (float)((double)G * sz);
+    }
+  }
+}
+
+}  // namespace nbh
+
+using namespace nbh;
+
+struct nbody_hip_grid {
+  nbody_hip_ctx* ctx = nullptr;
+  size_t max_particles = 0;
+  float cell_size = 1.0f;
+  // device
+  unsigned int* d_enc = nullptr;       // 6 ordered-int bbox words
+  GridInfo* d_info = nullptr;
+  GridInfo* h_info = nullptr;          // pinned
+  unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
+  int *d_idx_a = nullptr, *d_idx_b = nullptr;
+  float4* d_sorted = nullptr;
+  void* d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int *d_cell_start = nullptr, *d_cell_end = nullptr;  // lazily sized (inspection API only)
+  long long cell_capacity = 0;
+  bool ranges_valid = false;
+  // host mirror of the last build
+  GridInfo info{};
+  size_t built_count = 0;
+};
+
+static void grid_release(nbody_hip_grid* g) {
+  if (!g) return;
+  (void)hipFree(g->d_enc); (void)hipFree(g->d_info); (void)hipFree(g->d_keys_a);
+  (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_a); (void)hipFree(g->d_idx_b);
+  (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_cell_start);
+  (void)hipFree(g->d_cell_end);
+  if (g->h_info) (void)hipHostFree(g->h_info);
+  delete g;
+}
+
+extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, float cell_size,
+                                     nbody_hip_grid** out) {
+  if (!ctx || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  *out = nullptr;
+  if (max_particles == 0 || max_particles > 0x3fffffffu)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_particles out of range");
+  if (!(cell_size > 0.0f) || !(cell_size < INFINITY))
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Spatial hash cell size must be positive and finite");
+  NBH_HIP(hipSetDevice(ctx->device));
+  nbody_hip_grid* g = new nbody_hip_grid();
+  g->ctx = ctx;
+  g->max_particles = max_particles;
+  g->cell_size = cell_size;
+  const size_t n = max_particles;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_enc), 8 * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_info), sizeof(GridInfo));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_info), sizeof(GridInfo), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_keys_a), n * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_keys_b), n * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_idx_a), n * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_idx_b), n * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_sorted), n * sizeof(float4));
+  if (e == hipSuccess) {
+    size_t tmp = 0;
+    e = rocprim::radix_sort_pairs(nullptr, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
+                                  0, 32, ctx->stream);
+    if (e == hipSuccess) {
+      g->sort_tmp_bytes = tmp;
+      e = hipMalloc(&g->d_sort_tmp, tmp > 0 ? tmp : 16);
+    }
+  }
+  if (e != hipSuccess) {
+    grid_release(g);
+    return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
+                    "spatial hash grid allocation: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_destroy(nbody_hip_grid* g) {
+  if (!g) return NBODY_HIP_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  grid_release(g);
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!(cell_size > 0.0f) || !(cell_size < INFINITY))
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Spatial hash cell size must be positive and finite");
+  g->cell_size = cell_size;
+  return NBODY_HIP_OK;
+}
+
+static int bits_for(long long total) {
+  int b = 1;
+  while ((1LL << b) < total && b < 32) b++;
+  return b;
+}
+
+extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data* d) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  const size_t n = d->count;
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the grid's capacity %zu "
+                    "(sized from the first count seen, ref: force_spatial_hash.cu:372-374)", n, g->max_particles);
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
+
+  const int ni = (int)n;
+  const int blocks = (ni + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, g->d_enc);
+  hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, st, posm, ni, g->d_enc);
+  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info);
+  NBH_LAUNCH_CHECK();
+  // the one host round trip of the build: the grid size decides validity (and, for the
+  // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
+  NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
+  NBH_HIP(hipStreamSynchronize(st));
+  g->info = *g->h_info;
+  if (g->info.total > 100000000LL)  // :252-254
+    return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
+
+  hipLaunchKernelGGL(assign_cells_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_info,
+                     g->cell_size, g->d_keys_a, g->d_idx_a);
+  NBH_LAUNCH_CHECK();
+  size_t tmp = g->sort_tmp_bytes;
+  NBH_HIP(rocprim::radix_sort_pairs(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a,
+                                    g->d_idx_b, n, 0, bits_for(g->info.total), st));
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni,
+                     g->d_sorted);
+  NBH_LAUNCH_CHECK();
+  g->built_count = n;
+  g->ranges_valid = false;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_compute_forces(nbody_hip_grid* g, nbody_particle_data* d, float cutoff,
+                                             float G, float eps) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (g->built_count == 0 || g->built_count != d->count)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid was not built for this particle set");
+  if (!d->acc_x || !d->acc_y || !d->acc_z) return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  if (!(cutoff > 0.0f) || !(cutoff < INFINITY))
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Spatial hash cutoff must be positive and finite");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  const int n = (int)g->built_count;
+  const int gx = g->info.dims[0], gy = g->info.dims[1], gz = g->info.dims[2];
+  // run width: aim for ~128 targets per workgroup at the mean occupancy
+  const double rho = (double)n / (double)g->info.total;
+  int W = rho > 0 ? (int)(128.0 / rho + 0.5) : gx;
+  if (W < 1) W = 1;
+  if (W > gx) W = gx;
+  if (W > 64) W = 64;
+  const dim3 grid((gx + W - 1) / W, gy, gz);
+  if (grid.y > 65535u || grid.z > 65535u)
+    return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
+  const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;  // :312-313
+  const bool guard = eps2 < 1e-12f;
+  const bool strict = cutoff > g->cell_size;
+#define NBH_HASH_LAUNCH(GD, ST)                                                                   \
+  hipLaunchKernelGGL((hash_force_kernel<GD, ST>), grid, dim3(kBlock), 0, ctx->stream, g->d_sorted, \
+                     g->d_keys_b, g->d_idx_b, n, g->d_info, W, cutoff2, eps2, G, d->acc_x,        \
+                     d->acc_y, d->acc_z)
+  if (guard) { if (strict) NBH_HASH_LAUNCH(true, true); else NBH_HASH_LAUNCH(true, false); }
+  else       { if (strict) NBH_HASH_LAUNCH(false, true); else NBH_HASH_LAUNCH(false, false); }
+#undef NBH_HASH_LAUNCH
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_info(const nbody_hip_grid* g, int dims[3], int* total_cells,
+                                   float bbox_min[3], float bbox_max[3]) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  for (int a = 0; a < 3; a++) {
+    if (dims) dims[a] = g->built_count ? g->info.dims[a] : 0;
+    if (bbox_min) bbox_min[a] = g->info.bmin[a];
+    if (bbox_max) bbox_max[a] = g->info.bmax[a];
+  }
+  if (total_cells) *total_cells = g->built_count ? (int)g->info.total : 0;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_copy_cell_data(nbody_hip_grid* g, int* cell_start, int* cell_end,
+                                             int* particle_cells, int* sorted_indices) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid has not been built");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  const int n = (int)g->built_count;
+  const long long total = g->info.total;
+  const int blocks = (n + kBlock - 1) / kBlock;
+  if (cell_start || cell_end) {
+    if (total > g->cell_capacity) {
+      NBH_HIP(hipDeviceSynchronize());
+      (void)hipFree(g->d_cell_start); (void)hipFree(g->d_cell_end);
+      g->d_cell_start = g->d_cell_end = nullptr;
+      g->cell_capacity = 0;
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_start), total * sizeof(int)));
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_end), total * sizeof(int)));
+      g->cell_capacity = total;
+      g->ranges_valid = false;
+    }
+    if (!g->ranges_valid) {
+      NBH_HIP(hipMemsetAsync(g->d_cell_start, 0, total * sizeof(int), ctx->stream));
+      NBH_HIP(hipMemsetAsync(g->d_cell_end, 0, total * sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(cell_ranges_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->d_keys_b, n,
+                         g->d_cell_start, g->d_cell_end);
+      NBH_LAUNCH_CHECK();
+      g->ranges_valid = true;
+    }
+    if (cell_start) NBH_HIP(hipMemcpyAsync(cell_start, g->d_cell_start, total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (cell_end) NBH_HIP(hipMemcpyAsync(cell_end, g->d_cell_end, total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (particle_cells) {
+    // keys_a still holds the unsorted cell ids (radix_sort_pairs does not modify its input)
+    NBH_HIP(hipMemcpyAsync(particle_cells, g->d_keys_a, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (sorted_indices)
+    NBH_HIP(hipMemcpyAsync(sorted_indices, g->d_idx_b, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NBH_HIP(hipStreamSynchronize(ctx->stream));
+  return NBODY_HIP_OK;
+}

@@ -356,14 +356,25 @@ ORACLE_API void oracle_assign_cells(size_t n, const float* x, const float* y, co
   for (size_t i = 0; i < n; i++) cell_of[i] = oracle_cell_index(x[i], y[i], z[i], bmin, cell_size, dims);
 }
 
+/* Grid of SpatialHashGrid::build: bounding box padded by 0.001 on every side
+ * (force_spatial_hash.cu:225-231), then dims = ceil(extent / cell) + 1 (:244-246). */
+ORACLE_API void oracle_hash_grid(size_t n, const float* x, const float* y, const float* z,
+                                 float cell_size, float bmin[3], float bmax[3], int dims[3]) {
+  oracle_bbox(n, x, y, z, bmin, bmax);
+  for (int a = 0; a < 3; a++) {
+    bmin[a] -= 0.001f;
+    bmax[a] += 0.001f;
+  }
+  oracle_grid_dims(bmin, bmax, cell_size, dims);
+}
+
 ORACLE_API int oracle_spatial_hash_forces(size_t n, const float* x, const float* y,
                                           const float* z, const float* m, float* ax, float* ay,
                                           float* az, float G, float eps2, float cell_size,
                                           float cutoff) {
   float bmin[3], bmax[3];
   int dims[3];
-  oracle_bbox(n, x, y, z, bmin, bmax);
-  oracle_grid_dims(bmin, bmax, cell_size, dims);
+  oracle_hash_grid(n, x, y, z, cell_size, bmin, bmax, dims);
   long long cells = (long long)dims[0] * dims[1] * dims[2];
   if (cells > 100000000LL) return -1; /* force_spatial_hash.cu:252-254 */
   int* cell_of = (int*)malloc(n * sizeof(int));

@@ -45,6 +45,7 @@ class Oracle:
         L.oracle_cell_index.argtypes = [C.c_float, C.c_float, C.c_float, _f3, C.c_float, _i3]
         L.oracle_cell_index.restype = C.c_int
         L.oracle_assign_cells.argtypes = [C.c_size_t, _f, _f, _f, _f3, C.c_float, _i3, _i32]
+        L.oracle_hash_grid.argtypes = [C.c_size_t, _f, _f, _f, C.c_float, _f3, _f3, _i3]
         L.oracle_spatial_hash_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, _f, _f, _f, C.c_float,
                                                  C.c_float, C.c_float, C.c_float]
         L.oracle_spatial_hash_forces.restype = C.c_int
@@ -118,6 +119,11 @@ class Oracle:
         lo, hi = _f3(), _f3()
         self.L.oracle_bbox(x.size, x, y, z, lo, hi)
         return list(lo), list(hi)
+
+    def hash_grid(self, x, y, z, cell):
+        lo, hi, d = _f3(), _f3(), _i3()
+        self.L.oracle_hash_grid(x.size, x, y, z, cell, lo, hi, d)
+        return list(lo), list(hi), list(d)
 
     def spatial_hash_forces(self, x, y, z, m, G, eps2, cell, cutoff):
         ax, ay, az = (np.empty(x.size, np.float32) for _ in range(3))

@@ -1,0 +1,169 @@
+"""Spatial-hash path (through the C ABI) against the oracle and the reference's own tests
+(tests/test_spatial_hash.cpp).  The reference pins this path only structurally (partition
+property, non-zero forces); numeric parity vs the oracle's restatement of
+force_spatial_hash.cu:83-152 is added here (tolerance 1e-5 relative per body, fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import acc_of, rel_err, to_device
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+# tests/test_spatial_hash.cpp:15-36 GridConstruction + :53-83 ComputeForces
+def test_grid_construction_and_finite_forces(nb, ctx):
+    ic = nb.ic.sphere(100, seed=42, radius=5.0)
+    d, h = to_device(nb, ic)
+    grid = nb.SpatialHashGrid(100, 1.0)
+    grid.build(d)
+    assert grid.getTotalCells() > 0
+    calc = nb.SpatialHashCalculator(1.0, 2.0)
+    calc.setGravitationalConstant(1.0)
+    calc.setSofteningParameter(0.1)
+    calc.computeForces(d)
+    assert np.all(np.isfinite(acc_of(d)))
+    assert calc.getMethod() == nb.ForceMethod.SPATIAL_HASH
+
+
+# tests/test_spatial_hash.cpp:38-51 CellIndexCalculation
+def test_cell_index_kats(nb):
+    assert nb.SpatialHashGrid.getCellIndex(0.5, 0.5, 0.5, 2.0) == (0, 0, 0)
+    assert nb.SpatialHashGrid.getCellIndex(2.5, 4.5, 6.5, 2.0) == (1, 2, 3)
+
+
+# tests/test_spatial_hash.cpp:89-130: every particle in exactly one cell, inside its bounds
+@pytest.mark.parametrize("n,cell,seed", [(50, 1.0, 1), (500, 2.0, 2), (3000, 0.7, 3)])
+def test_cell_assignment_property(nb, oracle, ctx, n, cell, seed):
+    rng = np.random.default_rng(seed)
+    ic = nb.ic.uniform_box(n, seed=seed, lo=-10, hi=10)
+    d, h = to_device(nb, ic)
+    grid = nb.SpatialHashGrid(n, cell)
+    grid.build(d)
+    cs, ce, pc, si = grid.copyCellDataToHost()
+    dims, total = grid.getGridDims(), grid.getTotalCells()
+    # grid geometry equals the oracle's restatement of build() (:225-246)
+    lo, hi, odims = oracle.hash_grid(ic["pos_x"], ic["pos_y"], ic["pos_z"], cell)
+    assert list(dims) == odims and total == odims[0] * odims[1] * odims[2]
+    glo, ghi = grid.getBoundingBox()
+    assert np.allclose(glo, lo, atol=0) and np.allclose(ghi, hi, atol=0)
+    # bit-exact cell ids
+    import oracle_bind as ob
+    ocells = np.empty(n, np.int32)
+    oracle.L.oracle_assign_cells(n, ic["pos_x"], ic["pos_y"], ic["pos_z"], ob._f3(*lo), cell,
+                                 ob._i3(*odims), ocells)
+    assert np.array_equal(pc, ocells)
+    # partition: sorted_indices is a permutation, each body appears in the range of its own cell
+    assert np.array_equal(np.sort(si), np.arange(n))
+    counts = ce - cs
+    assert counts.sum() == n and np.all(counts >= 0)
+    for c in np.nonzero(counts)[0][:200]:
+        members = si[cs[c]:ce[c]]
+        assert np.all(pc[members] == c)
+        assert np.all(np.diff(members) > 0)  # stable sort: index order inside a cell
+    assert grid.verifyCellAssignment(h)
+
+
+# tests/test_spatial_hash.cpp:134-182: some force is non-zero when bodies are within the cutoff
+def test_forces_nonzero_property(nb, ctx):
+    ic = nb.ic.uniform_box(64, seed=9, lo=-1, hi=1)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(1.0, 2.0)
+    calc.setSofteningParameter(0.1)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+
+
+# numeric parity with the oracle: cutoff <= cell (complete search), cutoff > cell (the
+# reference's 27-cell search misses pairs: reproduced), tiny eps, and dense cells
+@pytest.mark.parametrize("n,box,cell,cutoff,eps,tol", [
+    (4000, 6.0, 1.0, 1.0, 0.01, TOL),
+    (4000, 6.0, 1.0, 2.0, 0.01, TOL),     # reference defaults: cutoff 2 > cell 1
+    (3000, 4.0, 0.5, 0.75, 0.1, TOL),
+    (2000, 2.0, 1.5, 1.0, 0.0, TOL),      # eps = 0: guard variant
+    # ~190 bodies per cell and eps far below the inter-body distance: ~5000 fp32 terms of size
+    # up to 400 per body cancelling to |a| ~ 100; fp32 partial sums (folded to fp64 every 64
+    # sources) limit agreement with the fp64-accumulated oracle to a few 1e-6 typical, 2e-5 max
+    (5000, 1.5, 1.0, 1.0, 0.05, 2e-5),
+    (257, 30.0, 1.0, 1.0, 0.01, TOL),     # sparse: most cells empty
+])
+def test_forces_match_oracle(nb, oracle, ctx, n, box, cell, cutoff, eps, tol):
+    ic = nb.ic.uniform_box(n, seed=n, lo=-box, hi=box, min_mass=0.5, max_mass=1.5)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(cell, cutoff)
+    calc.setGravitationalConstant(1.3)
+    calc.setSofteningParameter(eps)
+    calc.computeForces(d)
+    a = acc_of(d)
+    eps2 = float(np.float32(eps) * np.float32(eps))
+    ref = np.stack(oracle.spatial_hash_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"],
+                                              1.3, eps2, cell, cutoff), 1)
+    nz = np.linalg.norm(ref, axis=1) > 0
+    assert np.all(a[~nz] == 0)
+    if nz.any():
+        e = rel_err(a[nz], ref[nz])
+        assert e.max() < tol and np.median(e) < 1e-6
+    # determinism: a second evaluation is bitwise identical (stable binning)
+    calc.computeForces(d)
+    assert np.array_equal(acc_of(d), a)
+
+
+# clustered input (Plummer): very uneven cell occupancy
+def test_plummer_clustered(nb, oracle, ctx):
+    n = 20000
+    ic = nb.ic.plummer(n, seed=4)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(0.5, 0.5)
+    calc.setSofteningParameter(0.01)
+    calc.computeForces(d)
+    a = acc_of(d)
+    ref = np.stack(oracle.spatial_hash_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"],
+                                              1.0, float(np.float32(0.01) ** 2), 0.5, 0.5), 1)
+    nz = np.linalg.norm(ref, axis=1) > 0
+    assert rel_err(a[nz], ref[nz]).max() < TOL
+    # and equals the direct sum restricted to the cutoff (27-cell search is complete here)
+    idx = np.arange(0, n, 37)
+    dc = np.stack(oracle.direct_cutoff_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
+                                              1.0, float(np.float32(0.01) ** 2), 0.5), 1)
+    keep = np.linalg.norm(dc, axis=1) > 0
+    assert rel_err(a[idx][keep], dc[keep]).max() < TOL
+
+
+def test_error_behaviour(nb, ctx):
+    with pytest.raises(nb.ValidationException):
+        nb.SpatialHashGrid(100, 0.0)
+    # > 1e8 cells (force_spatial_hash.cu:252-254)
+    ic = nb.ic.uniform_box(100, seed=1, lo=-500, hi=500)
+    d, _ = to_device(nb, ic)
+    grid = nb.SpatialHashGrid(100, 1.0)
+    with pytest.raises(nb.ResourceException):
+        grid.build(d)
+    # capacity is fixed at creation (ref: sized from the first count, :372-374)
+    big, _ = to_device(nb, nb.ic.uniform_box(200, seed=2, lo=-5, hi=5))
+    with pytest.raises(nb.ValidationException):
+        grid.build(big)
+    # factory
+    cfg = nb.SimulationConfig(force_method=nb.ForceMethod.SPATIAL_HASH, spatial_hash_cell_size=2.0,
+                              spatial_hash_cutoff=1.5, softening=0.05, G=2.0)
+    calc = nb.createForceCalculator(cfg.force_method, cfg)
+    assert isinstance(calc, nb.SpatialHashCalculator)
+    assert (calc.getCellSize(), calc.getCutoffRadius()) == (2.0, 1.5)
+    assert calc.getGravitationalConstant() == 2.0 and calc.getSofteningParameter() == pytest.approx(0.05)
+
+
+# BASELINE config 5 shape on one GPU at reduced size + the full per-GPU share
+@pytest.mark.parametrize("n,half", [(524288, 16.0)])
+def test_uniform_box_16_per_cell(nb, oracle, ctx, n, half):
+    ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)  # 16 bodies per unit volume
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(1.0, 1.0)
+    calc.setSofteningParameter(0.01)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert np.all(np.isfinite(a))
+    idx = np.arange(0, n, 997)
+    dc = np.stack(oracle.direct_cutoff_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
+                                              1.0, float(np.float32(0.01) ** 2), 1.0), 1)
+    assert rel_err(a[idx], dc).max() < TOL
