@@ -199,6 +199,36 @@ NBODY_HIP_API int nbody_hip_grid_info(const nbody_hip_grid* grid, int dims[3], i
 NBODY_HIP_API int nbody_hip_grid_copy_cell_data(nbody_hip_grid* grid, int* cell_start, int* cell_end,
                                                 int* particle_cells, int* sorted_indices);
 
+/* ---- a8: Barnes-Hut (ref: BarnesHutTree / BarnesHutCalculator,
+ *          src/cuda/force_barnes_hut.cu:204-532, include/nbody/barnes_hut_tree.hpp:9-81) ---- */
+
+typedef struct nbody_hip_tree nbody_hip_tree;
+
+/* ref: BarnesHutTree(max_particles) :204-210 */
+NBODY_HIP_API int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, nbody_hip_tree** out);
+NBODY_HIP_API int nbody_hip_tree_destroy(nbody_hip_tree* tree);
+/* Tree shape: levels below the root (1..10, default 10 = 30-bit Morton keys; the reference caps
+ * its insertion at depth 20, :363) and the largest body count a leaf may hold (default 1, as in
+ * the reference, where a leaf holds one particle; at the deepest level a leaf keeps whatever
+ * falls into its cell).  Re-sizes the node arrays; the tree must be rebuilt afterwards. */
+NBODY_HIP_API int nbody_hip_tree_set_params(nbody_hip_tree* tree, int max_depth, int leaf_max);
+/* ref: BarnesHutTree::build :282-289 -- bounding box, Morton keys, sort, octree, monopoles; all on
+ * the device, no host round trip (the reference crosses PCIe >= 17 times here). */
+NBODY_HIP_API int nbody_hip_tree_build(nbody_hip_tree* tree, const nbody_particle_data* d);
+/* ref: BarnesHutTree::computeForces(d_particles, theta, G, eps) :488-498 -- OVERWRITES acc_*. */
+NBODY_HIP_API int nbody_hip_tree_compute_forces(nbody_hip_tree* tree, nbody_particle_data* d,
+                                                float theta, float G, float eps);
+/* ref: getNodeCount (barnes_hut_tree.hpp:41) and the root mass used by verifyMassConservation
+ * (:511-519); plus node visits (per wave) of the last traversal and the first node id of every
+ * level (12 ints).  Any output may be NULL.  Blocking. */
+NBODY_HIP_API int nbody_hip_tree_stats(nbody_hip_tree* tree, int* node_count, float* root_mass,
+                                       unsigned long long* nodes_visited, int level_base[12]);
+/* ref: copyNodesToHost / getNodes :500-503 -- writes the tree into HOST memory in the reference's
+ * OctreeNode layout (76 bytes, barnes_hut_tree.hpp:9-30), children indexed by octant; optionally
+ * the Morton order (sorted position -> body index, `count` ints).  Blocking. */
+NBODY_HIP_API int nbody_hip_tree_copy_nodes(nbody_hip_tree* tree, void* host_nodes, int capacity_nodes,
+                                            int* sorted_indices);
+
 /* ---- measurement helpers -------------------------------------------------- */
 
 /* Runs the direct-force kernel `iters` times back to back on the context's stream between

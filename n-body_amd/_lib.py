@@ -87,6 +87,14 @@ PROTOTYPES = {
     "nbody_hip_grid_info": (C.c_int, [_P, C.POINTER(C.c_int * 3), C.POINTER(C.c_int),
                                       C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
     "nbody_hip_grid_copy_cell_data": (C.c_int, [_P, _P, _P, _P, _P]),
+    "nbody_hip_tree_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "nbody_hip_tree_destroy": (C.c_int, [_P]),
+    "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),
+    "nbody_hip_tree_build": (C.c_int, [_P, _PD]),
+    "nbody_hip_tree_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
+    "nbody_hip_tree_stats": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_ulonglong), C.POINTER(C.c_int * 12)]),
+    "nbody_hip_tree_copy_nodes": (C.c_int, [_P, _P, C.c_int, _P]),
     "nbody_hip_time_direct_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_float,
                                                C.c_float, C.c_int, C.POINTER(C.c_float)]),
     "nbody_hip_direct_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),

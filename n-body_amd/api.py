@@ -433,11 +433,118 @@ class SpatialHashCalculator(ForceCalculator):
         return self.grid_
 
 
+# include/nbody/barnes_hut_tree.hpp:9-30 -- 76 bytes
+OCTREE_NODE_DTYPE = np.dtype([("center", np.float32, 3), ("half_size", np.float32),
+                              ("center_of_mass", np.float32, 3), ("total_mass", np.float32),
+                              ("children", np.int32, 8), ("particle_index", np.int32),
+                              ("is_leaf", np.bool_), ("_pad", np.uint8, 3),
+                              ("particle_count", np.int32)])
+assert OCTREE_NODE_DTYPE.itemsize == 76
+
+
+class BarnesHutTree:
+    """barnes_hut_tree.hpp:33-81 / force_barnes_hut.cu:204-519."""
+
+    def __init__(self, max_particles: int, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.max_particles_ = int(max_particles)
+        h = C.c_void_p()
+        check(self.ctx._lib.nbody_hip_tree_create(self.ctx.handle, self.max_particles_, C.byref(h)))
+        self._h = h
+        self._count = 0
+        self.h_nodes_ = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.ctx._lib.nbody_hip_tree_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def setParams(self, max_depth: int = 10, leaf_max: int = 1):
+        check(self.ctx._lib.nbody_hip_tree_set_params(self._h, max_depth, leaf_max))
+
+    def build(self, d_particles: ParticleData):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_tree_build(self._h, C.byref(s)))
+        self._count = d_particles.count
+
+    def computeForces(self, d_particles: ParticleData, theta: float, G: float, eps: float):
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_tree_compute_forces(self._h, C.byref(s), theta, G, eps))
+
+    def stats(self):
+        nc, rm, nv = C.c_int(), C.c_float(), C.c_ulonglong()
+        lb = (C.c_int * 12)()
+        check(self.ctx._lib.nbody_hip_tree_stats(self._h, C.byref(nc), C.byref(rm), C.byref(nv),
+                                                 C.byref(lb)))
+        return {"node_count": nc.value, "root_mass": rm.value, "nodes_visited": nv.value,
+                "level_base": list(lb)}
+
+    def getNodeCount(self) -> int:
+        return self.stats()["node_count"]
+
+    def copyNodesToHost(self):
+        n = self.getNodeCount()
+        nodes = np.zeros(n, dtype=OCTREE_NODE_DTYPE)
+        order = np.empty(self._count, np.int32)
+        check(self.ctx._lib.nbody_hip_tree_copy_nodes(self._h, nodes.ctypes.data, n, order.ctypes.data))
+        self.h_nodes_ = nodes
+        self.sorted_indices_ = order
+        return nodes
+
+    def getNodes(self):
+        return self.h_nodes_
+
+    def verifyTreeStructure(self) -> bool:
+        return self.getNodeCount() > 0  # force_barnes_hut.cu:505-509
+
+    def verifyMassConservation(self, h_particles: ParticleData) -> bool:
+        """force_barnes_hut.cu:511-519: |sum m - root mass| < 0.001 sum m (fp32 sum)."""
+        total = np.float32(0)
+        for v in h_particles.mass[: h_particles.count]:
+            total = np.float32(total + v)
+        root = np.float32(self.stats()["root_mass"])
+        return bool(abs(total - root) < np.float32(0.001) * total)
+
+
+class BarnesHutCalculator(ForceCalculator):
+    """force_calculator.hpp:136-165 / force_barnes_hut.cu:521-532: the tree is created lazily at
+    the first computeForces and sized from that particle count."""
+
+    def __init__(self, theta: float = 0.5, ctx: Context | None = None):
+        super().__init__(ctx)
+        self.tree_ = None
+        self.theta_ = float(theta)
+
+    def computeForces(self, d_particles: ParticleData):
+        if self.tree_ is None:
+            self.tree_ = BarnesHutTree(d_particles.count, self.ctx)
+        self.tree_.build(d_particles)
+        self.tree_.computeForces(d_particles, self.theta_, self.G_, self.softening_eps_)
+
+    def getMethod(self):
+        return ForceMethod.BARNES_HUT
+
+    def setTheta(self, theta):
+        self.theta_ = float(theta)
+
+    def getTheta(self):
+        return self.theta_
+
+    def getTree(self):
+        return self.tree_
+
+
 def createForceCalculator(method: ForceMethod, config: SimulationConfig,
                           ctx: Context | None = None) -> ForceCalculator:
     """force_spatial_hash.cu:380-401: unknown enumerators fall back to Direct."""
     if method == ForceMethod.BARNES_HUT:
-        raise NotImplementedError("BARNES_HUT is not built yet in this tree")
+        calc = BarnesHutCalculator(config.barnes_hut_theta, ctx)
+        calc.setGravitationalConstant(config.G)
+        calc.setSofteningParameter(config.softening)
+        return calc
     if method == ForceMethod.SPATIAL_HASH:
         calc = SpatialHashCalculator(config.spatial_hash_cell_size, config.spatial_hash_cutoff, ctx)
         calc.setGravitationalConstant(config.G)

@@ -1,0 +1,593 @@
+// barnes_hut.hip -- on-device octree build and wave-cooperative traversal, gfx950.
+//
+// Replaces BarnesHutTree / BarnesHutCalculator of the reference
+// (src/cuda/force_barnes_hut.cu:204-532).  The reference builds its tree on the HOST with
+// >= 17 PCIe crossings per step (:324-333, :434, :443-450, :484) and its insertion loop never
+// subdivides an occupied leaf (:363-396), so only the CONTRACT is kept:
+//   root cube   centre = bbox midpoint, half = max extent / 2 + 0.001           (:339-344)
+//   Morton      10 bits per axis, x|y|z interleave                              (:23-38)
+//   traversal   skip massless nodes; accept a node if it is a leaf or
+//               (2 half)^2 / (d^2 + eps^2) < theta^2; skip the body itself      (:160-195)
+// Everything runs on the device with no host round trip:
+//   keys  -> stable radix sort (rocPRIM) -> bodies reordered into Morton order (float4)
+//   build    level by level from the sorted keys: a body opens a node at level L when its
+//            3L-bit key prefix differs from its predecessor's and its level-(L-1) cell holds
+//            more than `leaf_max` bodies; node ids come from a prefix scan, so the nodes of a
+//            level are in Morton order and the children of a node are CONSECUTIVE
+//   monopoles bottom-up per level in fp64 (children summed in octant order)
+//   traversal one wave walks the tree for 64 Morton-adjacent bodies with ONE shared stack in
+//            LDS.  A stack entry is (first child, child count, 64-bit lane mask): lanes in the
+//            mask test the node; lanes that accept it accumulate its monopole and drop out of
+//            the mask; if any lane still needs it opened (ballot) its children are pushed with
+//            the remaining mask.  Every body therefore gets exactly the interaction list of a
+//            private depth-first walk, but node records are wave-uniform (scalar-cache) loads
+//            and there is no divergence and no private stack (the reference keeps
+//            `int stack[256]` per thread in scratch and drops children when it overflows,
+//            :147-153,:186-194).
+//
+// Roofline: build = HBM streaming + sort (~100 B/body); traversal = latency/L2 bound:
+// 32 B per node visited per WAVE (not per body).
+
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace nbh {
+
+constexpr int kMaxDepth = 10;      // 30-bit Morton keys
+constexpr int kStack = 8 * (kMaxDepth + 2);
+
+struct TreeRoot {
+  float lo[3];
+  float half;
+  float scale;  // 1024 / (2 half)
+  int pad[3];
+};
+
+__global__ void tree_root_kernel(const unsigned int* __restrict__ enc, TreeRoot* __restrict__ root,
+                                 int* __restrict__ level_base) {
+  if (threadIdx.x != 0) return;
+  float ext = 0.f, c[3];
+  for (int a = 0; a < 3; a++) {
+    const float lo = ordered_to_float(enc[a]), hi = ordered_to_float(enc[3 + a]);
+    c[a] = (lo + hi) * 0.5f;               // :339-340
+    ext = fmaxf(ext, hi - lo);
+  }
+  const float half = ext * 0.5f + 0.001f;  // :343
+  for (int a = 0; a < 3; a++) root->lo[a] = c[a] - half;
+  root->half = half;
+  root->scale = 1024.0f / (2.0f * half);
+  level_base[0] = 0;
+}
+
+__device__ __forceinline__ unsigned int expand_bits10(unsigned int v) {  // :23-29
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ posm, int n,
+                                                        const TreeRoot* __restrict__ root,
+                                                        unsigned int* __restrict__ keys,
+                                                        int* __restrict__ idx) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i];
+  const float s = root->scale;
+  int qx = (int)((p.x - root->lo[0]) * s);
+  int qy = (int)((p.y - root->lo[1]) * s);
+  int qz = (int)((p.z - root->lo[2]) * s);
+  qx = min(max(qx, 0), 1023); qy = min(max(qy, 0), 1023); qz = min(max(qz, 0), 1023);
+  keys[i] = (expand_bits10((unsigned)qx) << 2) | (expand_bits10((unsigned)qy) << 1) |
+            expand_bits10((unsigned)qz);
+  idx[i] = i;
+}
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(const float4* __restrict__ posm,
+                                                        const int* __restrict__ idx, int n,
+                                                        float4* __restrict__ out) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < n) out[k] = posm[idx[k]];
+}
+
+// Per-node build records (SoA)
+struct TreeArrays {
+  int* first;       // first sorted body
+  int* last;        // one past the last sorted body
+  int* child0;      // id of the first child, -1 = leaf
+  int* child_last;  // id of the last child
+  float4* a;        // {com x, y, z, mass}                                   (traversal)
+  int4* b;          // {(2 half)^2 bits, first, count, child0 | nchild << 28} (traversal)
+  double4* m;       // fp64 monopole {com x, y, z, mass}
+};
+
+__device__ __forceinline__ bool is_head(const unsigned int* __restrict__ keys, int i, int shift) {
+  // shift == 30 (level 0): every 30-bit key has prefix 0 -> only body 0 opens the root
+  return i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift);
+}
+
+// level L, step 1: flag[i] = body i opens a node at this level
+__global__ __launch_bounds__(kBlock) void level_flag_kernel(const unsigned int* __restrict__ keys,
+                                                            int n, int level, int leaf_max,
+                                                            const int* __restrict__ nid_prev,
+                                                            TreeArrays t, int* __restrict__ flag) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  bool open = true;
+  if (level > 0) {
+    const int p = nid_prev[i];
+    open = p >= 0 && (t.last[p] - t.first[p]) > leaf_max;  // parent is an internal node
+  }
+  const int shift = 30 - 3 * level;
+  flag[i] = (open && is_head(keys, i, shift)) ? 1 : 0;
+}
+
+// level L, step 2: node ids from the inclusive scan; ranges and parent links
+__global__ __launch_bounds__(kBlock) void level_fill_kernel(const unsigned int* __restrict__ keys,
+                                                            int n, int level, int leaf_max,
+                                                            const int* __restrict__ nid_prev,
+                                                            const int* __restrict__ incl,
+                                                            TreeArrays t, int capacity,
+                                                            int* __restrict__ nid_cur,
+                                                            int* __restrict__ level_base) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int base = level_base[level];
+  if (i == n - 1) level_base[level + 1] = min(base + incl[n - 1], capacity);
+  bool open = true;
+  int p = -1;
+  if (level > 0) {
+    p = nid_prev[i];
+    open = p >= 0 && (t.last[p] - t.first[p]) > leaf_max;
+  }
+  int nid = -1;
+  if (open) {
+    nid = base + incl[i] - 1;
+    if (nid >= capacity) nid = -1;  // cannot happen with the capacity bound; never write past it
+  }
+  nid_cur[i] = nid;
+  if (nid < 0) return;
+  const int shift = 30 - 3 * level;
+  if (is_head(keys, i, shift)) t.first[nid] = i;
+  if (i == n - 1 || (keys[i + 1] >> shift) != (keys[i] >> shift)) t.last[nid] = i + 1;
+  if (p >= 0) {
+    if (i == t.first[p]) t.child0[p] = nid;
+    if (i + 1 == t.last[p]) t.child_last[p] = nid;
+  }
+}
+
+// monopoles of one level (deepest first) + the packed traversal records
+__global__ __launch_bounds__(kBlock) void level_monopole_kernel(int level,
+                                                                const int* __restrict__ level_base,
+                                                                const float4* __restrict__ sorted,
+                                                                const TreeRoot* __restrict__ root,
+                                                                TreeArrays t) {
+  const int lo = level_base[level], hi = level_base[level + 1];
+  for (int nid = lo + blockIdx.x * kBlock + threadIdx.x; nid < hi; nid += gridDim.x * kBlock) {
+    const int first = t.first[nid], cnt = t.last[nid] - first;
+    const int c0 = t.child0[nid];
+    double mx = 0.0, my = 0.0, mz = 0.0, ms = 0.0;
+    double4 mono;
+    int nchild = 0;
+    if (c0 < 0) {  // leaf: its bodies, in sorted order
+      for (int k = first; k < first + cnt; k++) {
+        const float4 p = sorted[k];
+        const double mb = (double)p.w;
+        mx += mb * (double)p.x; my += mb * (double)p.y; mz += mb * (double)p.z; ms += mb;
+      }
+      if (cnt == 1) {
+        const float4 p = sorted[first];
+        mono = make_double4((double)p.x, (double)p.y, (double)p.z, ms);
+      } else if (ms > 0.0) {
+        mono = make_double4(mx / ms, my / ms, mz / ms, ms);
+      } else {
+        mono = make_double4(0.0, 0.0, 0.0, 0.0);
+      }
+    } else {
+      const int c1 = t.child_last[nid];
+      nchild = c1 - c0 + 1;
+      for (int c = c0; c <= c1; c++) {  // consecutive ids = octant order
+        const double4 cm = t.m[c];
+        mx += cm.x * cm.w; my += cm.y * cm.w; mz += cm.z * cm.w; ms += cm.w;
+      }
+      mono = ms > 0.0 ? make_double4(mx / ms, my / ms, mz / ms, ms)
+                      : make_double4(0.0, 0.0, 0.0, 0.0);
+    }
+    t.m[nid] = mono;
+    t.a[nid] = make_float4((float)mono.x, (float)mono.y, (float)mono.z, (float)mono.w);
+    const float h = ldexpf(root->half, -level);
+    const float size = 2.0f * h;  // :168
+    t.b[nid] = make_int4(__float_as_int(size * size), first, cnt,
+                         c0 < 0 ? 0 : (int)((unsigned)c0 | ((unsigned)nchild << 28)));
+  }
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------------------
+// Traversal.  block = 256 = 4 independent waves; wave w of block b walks the tree for sorted
+// bodies [b*256 + w*64, +64).
+// ---------------------------------------------------------------------------------------
+template <bool GUARD>
+__global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
+    const float4* __restrict__ node_a, const int4* __restrict__ node_b,
+    const float4* __restrict__ sorted, const int* __restrict__ idx, int n, float theta2,
+    float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
+    float* __restrict__ acc_z, unsigned long long* __restrict__ visit_count) {
+#pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
+  __shared__ int4 stk[4][kStack];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x * kBlock + tid;
+  const bool valid = t < n;
+  float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) pi = sorted[t];
+  double sx = 0.0, sy = 0.0, sz = 0.0;  // fp32 sums of one sibling group are folded into fp64
+  const unsigned long long m0 = __ballot(valid);
+  if (m0 == 0ull) return;  // wave-uniform
+  int sp = 0;
+  if (lane == 0) stk[w][0] = make_int4(0, 1, (int)(unsigned)(m0 & 0xffffffffull), (int)(unsigned)(m0 >> 32));
+  sp = 1;
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long visited = 0;
+
+  while (sp > 0) {
+    sp--;
+    const int4 e = stk[w][sp];
+    const int c0 = rfl(e.x), cn = rfl(e.y);
+    const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.w) << 32) | (unsigned)rfl(e.z);
+    const bool in = (M >> lane) & 1ull;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int c = c0; c < c0 + cn; c++) {
+      const float4 A = node_a[c];  // wave-uniform address: scalar-cache loads
+      const int4 B = node_b[c];
+      visited++;
+      if (A.w == 0.0f) continue;   // :161-162 massless node
+      const int first = B.y, cnt = B.z;
+      const unsigned int ci = (unsigned int)B.w;
+      if (ci == 0u) {
+        // leaf: its bodies interact individually (exact), the body itself is skipped (:175)
+        for (int q = first; q < first + cnt; q++) {
+          const float4 s = sorted[q];
+          const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+          bool ok = in && (q != t);
+          if (GUARD) ok = ok && (d2 > 0.f);
+          const float f = ok ? (s.w * inv) * (inv * inv) : 0.f;
+          ax += f * dx; ay += f * dy; az += f * dz;
+        }
+        continue;
+      }
+      const float dx = A.x - pi.x, dy = A.y - pi.y, dz = A.z - pi.z;
+      const float dist2 = dx * dx + dy * dy + dz * dz + eps2;  // :165
+      const float size2 = __int_as_float(B.x);
+      const bool accept = in && (size2 / dist2 < theta2);       // :171-172
+      if (accept) {
+        const float inv = __builtin_amdgcn_rsqf(dist2);
+        const float f = (A.w * inv) * (inv * inv);
+        ax += f * dx; ay += f * dy; az += f * dz;
+      }
+      const unsigned long long O = __ballot(in && !accept);
+      if (O != 0ull) {
+        if (lane == 0)
+          stk[w][sp] = make_int4((int)(ci & 0x0fffffffu), (int)(ci >> 28),
+                                 (int)(unsigned)(O & 0xffffffffull), (int)(unsigned)(O >> 32));
+        sp++;
+      }
+    }
+    sx += (double)ax; sy += (double)ay; sz += (double)az;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (valid) {
+    const int i = idx[t];
+    acc_x[i] = (float)((double)G * sx);
+    acc_y[i] = (float)((double)G * sy);
+    acc_z[i] = (float)((double)G * sz);
+  }
+  if (visit_count && lane == 0) atomicAdd(visit_count, visited);
+}
+
+}  // namespace nbh
+
+using namespace nbh;
+
+// ref layout: OctreeNode, include/nbody/barnes_hut_tree.hpp:9-30 (76 bytes)
+struct RefOctreeNode {
+  float center[3]; float half_size; float com[3]; float total_mass;
+  int children[8]; int particle_index; bool is_leaf; int particle_count;
+};
+static_assert(sizeof(RefOctreeNode) == 76, "OctreeNode layout");
+
+struct nbody_hip_tree {
+  nbody_hip_ctx* ctx = nullptr;
+  size_t max_particles = 0;
+  int max_depth = kMaxDepth;
+  int leaf_max = 1;
+  int capacity = 0;
+  unsigned int* d_enc = nullptr;
+  TreeRoot* d_root = nullptr;
+  int* d_level_base = nullptr;  // kMaxDepth + 2 ints
+  unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
+  int *d_idx_a = nullptr, *d_idx_b = nullptr;
+  float4* d_sorted = nullptr;
+  int *d_flag = nullptr, *d_incl = nullptr, *d_nid[2] = {nullptr, nullptr};
+  TreeArrays t{};
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  unsigned long long* d_visits = nullptr;
+  size_t built_count = 0;
+};
+
+static void tree_release(nbody_hip_tree* g) {
+  if (!g) return;
+  void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
+                  g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl, g->d_nid[0], g->d_nid[1],
+                  g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.a, g->t.b, g->t.m,
+                  g->d_tmp, g->d_visits};
+  for (void* p : ptrs) (void)hipFree(p);
+  delete g;
+}
+
+template <class T>
+static hipError_t dmalloc(T** p, size_t count) {
+  return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+static int tree_alloc_nodes(nbody_hip_tree* g) {
+  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.a, g->t.b, g->t.m};
+  for (void* p : ptrs) (void)hipFree(p);
+  g->t = TreeArrays{};
+  const size_t n = g->max_particles;
+  // leaves <= n; internal nodes per level <= n / (leaf_max + 1)
+  size_t cap = n + (size_t)(g->max_depth + 1) * (n / (size_t)(g->leaf_max + 1) + 1) + 16;
+  if (cap > 0x0fffffffu) cap = 0x0fffffffu;  // 28-bit child ids
+  g->capacity = (int)cap;
+  hipError_t e = dmalloc(&g->t.first, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.last, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.child0, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.child_last, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.a, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.b, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.m, cap);
+  if (e != hipSuccess)
+    return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
+                    "Barnes-Hut node allocation (%zu nodes): %s", cap, hipGetErrorString(e));
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, nbody_hip_tree** out) {
+  if (!ctx || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  *out = nullptr;
+  if (max_particles == 0 || max_particles > 0x07ffffffu)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_particles out of range");
+  NBH_HIP(hipSetDevice(ctx->device));
+  nbody_hip_tree* g = new nbody_hip_tree();
+  g->ctx = ctx;
+  g->max_particles = max_particles;
+  const size_t n = max_particles;
+  hipError_t e = dmalloc(&g->d_enc, 8);
+  if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
+  if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
+  if (e == hipSuccess) e = dmalloc(&g->d_keys_a, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_keys_b, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_idx_a, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_idx_b, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_sorted, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_flag, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_incl, n);
+  if (e == hipSuccess) e = dmalloc(&g->d_nid[0], n);
+  if (e == hipSuccess) e = dmalloc(&g->d_nid[1], n);
+  if (e == hipSuccess) e = dmalloc(&g->d_visits, 1);
+  if (e == hipSuccess) {
+    size_t t1 = 0, t2 = 0;
+    e = rocprim::radix_sort_pairs(nullptr, t1, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n, 0,
+                                  30, ctx->stream);
+    if (e == hipSuccess)
+      e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, n, rocprim::plus<int>(), ctx->stream);
+    g->tmp_bytes = t1 > t2 ? t1 : t2;
+    if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
+  }
+  if (e != hipSuccess) {
+    tree_release(g);
+    return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
+                    "Barnes-Hut tree allocation: %s", hipGetErrorString(e));
+  }
+  if (int rc = tree_alloc_nodes(g)) {
+    tree_release(g);
+    return rc;
+  }
+  *out = g;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_destroy(nbody_hip_tree* g) {
+  if (!g) return NBODY_HIP_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  tree_release(g);
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int leaf_max) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (max_depth < 1 || max_depth > kMaxDepth)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_depth must be in [1, %d]", kMaxDepth);
+  if (leaf_max < 1 || leaf_max > 1024)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "leaf_max must be in [1, 1024]");
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  NBH_HIP(hipStreamSynchronize(g->ctx->stream));
+  g->max_depth = max_depth;
+  g->leaf_max = leaf_max;
+  g->built_count = 0;
+  return tree_alloc_nodes(g);
+}
+
+extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data* d) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  const size_t n = d->count;
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the tree's capacity %zu "
+                    "(sized from the first count seen, ref: force_barnes_hut.cu:527-529)", n, g->max_particles);
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
+  const int ni = (int)n;
+  const int blocks = (ni + kBlock - 1) / kBlock;
+
+  if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+  hipLaunchKernelGGL(tree_root_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->d_root, g->d_level_base);
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_root,
+                     g->d_keys_a, g->d_idx_a);
+  NBH_LAUNCH_CHECK();
+  size_t tmp = g->tmp_bytes;
+  NBH_HIP(rocprim::radix_sort_pairs(g->d_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
+                                    0, 30, st));
+  hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
+  NBH_LAUNCH_CHECK();
+  NBH_HIP(hipMemsetAsync(g->t.child0, 0xff, (size_t)g->capacity * sizeof(int), st));  // -1 = leaf
+
+  for (int L = 0; L <= g->max_depth; L++) {
+    int* prev = g->d_nid[(L + 1) & 1];
+    int* cur = g->d_nid[L & 1];
+    // at the last level no node may open children: every node there is a leaf.  Levels beyond
+    // max_depth are not built, so a parent at max_depth keeps child0 = -1.
+    hipLaunchKernelGGL(level_flag_kernel, dim3(blocks), dim3(kBlock), 0, st, g->d_keys_b, ni, L,
+                       g->leaf_max, prev, g->t, g->d_flag);
+    tmp = g->tmp_bytes;
+    NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, g->d_flag, g->d_incl, n, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(level_fill_kernel, dim3(blocks), dim3(kBlock), 0, st, g->d_keys_b, ni, L,
+                       g->leaf_max, prev, g->d_incl, g->t, g->capacity, cur, g->d_level_base);
+    NBH_LAUNCH_CHECK();
+  }
+  for (int L = g->max_depth; L >= 0; L--) {
+    hipLaunchKernelGGL(level_monopole_kernel, dim3(L < 3 ? 2 : 1024), dim3(kBlock), 0, st, L,
+                       g->d_level_base, g->d_sorted, g->d_root, g->t);
+  }
+  NBH_LAUNCH_CHECK();
+  g->built_count = n;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_compute_forces(nbody_hip_tree* g, nbody_particle_data* d, float theta,
+                                             float G, float eps) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (g->built_count == 0 || g->built_count != d->count)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree was not built for this particle set");
+  if (!d->acc_x || !d->acc_y || !d->acc_z) return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  if (!(theta >= 0.0f) || theta > 2.0f)  // ref: validateTheta, error_handling.cpp:115-123
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Barnes-Hut theta must be between 0 and 2");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  const int n = (int)g->built_count;
+  const int blocks = (n + kBlock - 1) / kBlock;
+  const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
+  NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), ctx->stream));
+  if (eps2 < 1e-12f)
+    hipLaunchKernelGGL(bh_traverse_kernel<true>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.a,
+                       g->t.b, g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y,
+                       d->acc_z, g->d_visits);
+  else
+    hipLaunchKernelGGL(bh_traverse_kernel<false>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.a,
+                       g->t.b, g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y,
+                       d->acc_z, g->d_visits);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_stats(nbody_hip_tree* g, int* node_count, float* root_mass,
+                                    unsigned long long* nodes_visited_per_wave_total,
+                                    int level_base_out[12]) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree has not been built");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  NBH_HIP(hipStreamSynchronize(ctx->stream));
+  int lb[kMaxDepth + 3];
+  NBH_HIP(hipMemcpy(lb, g->d_level_base, sizeof(lb), hipMemcpyDeviceToHost));
+  if (node_count) *node_count = lb[g->max_depth + 1];
+  if (level_base_out)
+    for (int k = 0; k < 12; k++) level_base_out[k] = k <= g->max_depth + 1 ? lb[k] : lb[g->max_depth + 1];
+  if (root_mass) {
+    float4 a;
+    NBH_HIP(hipMemcpy(&a, g->t.a, sizeof(a), hipMemcpyDeviceToHost));
+    *root_mass = a.w;
+  }
+  if (nodes_visited_per_wave_total)
+    NBH_HIP(hipMemcpy(nodes_visited_per_wave_total, g->d_visits, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return NBODY_HIP_OK;
+}
+
+// ref: BarnesHutTree::copyNodesToHost / getNodes (force_barnes_hut.cu:500-503): the tree in the
+// reference's OctreeNode layout, children indexed by octant (x = bit 2, y = bit 1, z = bit 0).
+extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, int capacity_nodes,
+                                         int* sorted_indices) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree has not been built");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  NBH_HIP(hipStreamSynchronize(ctx->stream));
+  int lb[kMaxDepth + 3];
+  NBH_HIP(hipMemcpy(lb, g->d_level_base, sizeof(lb), hipMemcpyDeviceToHost));
+  const int count = lb[g->max_depth + 1];
+  const int n = (int)g->built_count;
+  if (sorted_indices)
+    NBH_HIP(hipMemcpy(sorted_indices, g->d_idx_b, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  if (!host_nodes) return NBODY_HIP_OK;
+  if (capacity_nodes < count)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "node buffer too small: %d < %d", capacity_nodes, count);
+  std::vector<float4> a(count);
+  std::vector<int4> b(count);
+  std::vector<unsigned int> keys(n);
+  std::vector<int> idx(n);
+  TreeRoot root;
+  NBH_HIP(hipMemcpy(a.data(), g->t.a, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(b.data(), g->t.b, (size_t)count * sizeof(int4), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(keys.data(), g->d_keys_b, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(idx.data(), g->d_idx_b, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(&root, g->d_root, sizeof(root), hipMemcpyDeviceToHost));
+  RefOctreeNode* out = static_cast<RefOctreeNode*>(host_nodes);
+  int level = 0;
+  for (int nid = 0; nid < count; nid++) {
+    while (level < g->max_depth && nid >= lb[level + 1]) level++;
+    RefOctreeNode& o = out[nid];
+    const int first = b[nid].y, cnt = b[nid].z;
+    const unsigned int ci = (unsigned int)b[nid].w;
+    const unsigned int k = keys[first];
+    unsigned int q[3] = {0, 0, 0};
+    for (int bit = 0; bit < 10; bit++) {
+      q[0] |= ((k >> (3 * bit + 2)) & 1u) << bit;
+      q[1] |= ((k >> (3 * bit + 1)) & 1u) << bit;
+      q[2] |= ((k >> (3 * bit + 0)) & 1u) << bit;
+    }
+    const float h = ldexpf(root.half, -level);
+    for (int ax = 0; ax < 3; ax++)
+      o.center[ax] = root.lo[ax] + ((float)(q[ax] >> (10 - level)) + 0.5f) * (2.0f * h);
+    o.half_size = h;
+    o.com[0] = a[nid].x; o.com[1] = a[nid].y; o.com[2] = a[nid].z;
+    o.total_mass = a[nid].w;
+    for (int c = 0; c < 8; c++) o.children[c] = -1;
+    o.is_leaf = ci == 0u;
+    o.particle_index = (o.is_leaf && cnt >= 1) ? idx[first] : -1;
+    o.particle_count = cnt;
+    if (!o.is_leaf) {
+      const int c0 = (int)(ci & 0x0fffffffu), nc = (int)(ci >> 28);
+      const int shift = 27 - 3 * level;
+      for (int c = c0; c < c0 + nc; c++) o.children[(keys[b[c].y] >> shift) & 7u] = c;
+    }
+  }
+  return NBODY_HIP_OK;
+}

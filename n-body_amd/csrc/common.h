@@ -71,6 +71,19 @@ int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
 int pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m,
               size_t n, float4* out);
 
+// spatial_hash.hip: order-preserving-integer bounding box of packed bodies into enc[6]
+// (min x,y,z then max x,y,z); decode with ordered_to_float on the device.
+int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc);
+
+__device__ __forceinline__ unsigned int float_to_ordered(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(unsigned int o) {
+  const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace nbh

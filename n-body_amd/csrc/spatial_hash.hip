@@ -36,15 +36,6 @@ namespace nbh {
 
 constexpr int HTS = 256;  // sources per LDS tile
 
-__device__ __forceinline__ unsigned int float_to_ordered(float f) {
-  const unsigned int u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ordered_to_float(unsigned int o) {
-  const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-  return __uint_as_float(u);
-}
-
 __global__ void bbox_init_kernel(unsigned int* enc) {
   if (threadIdx.x < 3) enc[threadIdx.x] = 0xffffffffu;      // mins
   else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;           // maxs
@@ -76,6 +67,15 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
       atomicMax(&enc[3 + a], float_to_ordered(hi[a]));
     }
   }
+}
+
+int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc) {
+  const int blocks = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
+  hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, ctx->stream,
+                     posm, n, enc);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
 }
 
 struct GridInfo {
@@ -368,8 +368,7 @@ extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data
 
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, g->d_enc);
-  hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, st, posm, ni, g->d_enc);
+  if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
   hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info);
   NBH_LAUNCH_CHECK();
   // the one host round trip of the build: the grid size decides validity (and, for the

@@ -451,130 +451,186 @@ ORACLE_API void oracle_direct_cutoff_forces(size_t n, const float* x, const floa
 /* ------------------------------------------------------------------------- */
 /* a8: Barnes-Hut.  The reference's host insertion (force_barnes_hut.cu:        */
 /*     363-396) never subdivides an occupied leaf, so only   */
-/*     its CONTRACT is followed: a correct octree over the bounding cube,       */
-/*     monopole (mass, centre of mass) per node, and the reference's traversal  */
-/*     rule :164-195 -- accept a node if it is a leaf or                        */
-/*     (2*half_size)^2 / (d^2 + eps^2) < theta^2, skip the body itself.         */
+/*     its CONTRACT is followed:                                                */
+/*       root cube   centre = bbox midpoint, half = max extent/2 + 0.001 (:339-344) */
+/*       octree      every cell with more than `leaf_max` bodies is split, down  */
+/*                   to `max_depth` levels (cells are addressed on the           */
+/*                   2^max_depth integer grid of the root cube, the Morton       */
+/*                   quantisation of :23-38 applied to the cube)                 */
+/*       monopoles   mass and centre of mass per node                            */
+/*       traversal   :164-195 -- skip massless nodes; accept a node if it is a   */
+/*                   leaf or (2 half)^2 / (d^2 + eps^2) < theta^2; a leaf's       */
+/*                   bodies interact individually, the body itself is skipped    */
+/*     The HIP path builds the same tree from sorted Morton keys, so the two     */
+/*     can be compared body by body.                                             */
 /* ------------------------------------------------------------------------- */
 typedef struct {
   float cx, cy, cz, half;
-  double mx, my, mz, mass; /* mass-weighted position sum, then COM */
+  double mx, my, mz, mass; /* centre of mass, mass */
   int child[8];
-  int body;  /* leaf: body index or -1 */
-  int nbody; /* bodies below */
+  int first, count; /* range of the Morton-sorted body list */
+  int is_leaf;
 } ONode;
 
 typedef struct {
   ONode* nodes;
   int count, cap;
+  const uint32_t* key;  /* sorted keys */
+  const int* order;     /* sorted position -> body index */
+  const float *x, *y, *z, *m;
+  float lo[3], half;
+  int max_depth, leaf_max;
 } OTree;
 
-static int otree_new(OTree* t, float cx, float cy, float cz, float half) {
+static uint32_t expand_bits10(uint32_t v) {
+  /* force_barnes_hut.cu:23-29 */
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+ORACLE_API void oracle_bh_root(size_t n, const float* x, const float* y, const float* z,
+                               float center[3], float* half) {
+  float bmin[3], bmax[3];
+  oracle_bbox(n, x, y, z, bmin, bmax);
+  float ext = 0.0f;
+  for (int a = 0; a < 3; a++) {
+    center[a] = (bmin[a] + bmax[a]) * 0.5f;
+    float e = bmax[a] - bmin[a];
+    if (e > ext) ext = e;
+  }
+  *half = ext * 0.5f + 0.001f;
+}
+
+ORACLE_API uint32_t oracle_bh_key(float px, float py, float pz, const float lo[3], float scale) {
+  int q[3];
+  const float p[3] = {px, py, pz};
+  for (int a = 0; a < 3; a++) {
+    float f = (p[a] - lo[a]) * scale;
+    int v = (int)f;
+    q[a] = v < 0 ? 0 : (v > 1023 ? 1023 : v);
+  }
+  return (expand_bits10((uint32_t)q[0]) << 2) | (expand_bits10((uint32_t)q[1]) << 1) |
+         expand_bits10((uint32_t)q[2]);
+}
+
+static int otree_new(OTree* t) {
   if (t->count == t->cap) {
     t->cap = t->cap ? t->cap * 2 : 1024;
     t->nodes = (ONode*)realloc(t->nodes, (size_t)t->cap * sizeof(ONode));
   }
   ONode* nd = &t->nodes[t->count];
   memset(nd, 0, sizeof(*nd));
-  nd->cx = cx; nd->cy = cy; nd->cz = cz; nd->half = half;
   for (int k = 0; k < 8; k++) nd->child[k] = -1;
-  nd->body = -1;
   return t->count++;
 }
 
-static int octant(const ONode* nd, float px, float py, float pz) {
-  return (px >= nd->cx ? 1 : 0) | (py >= nd->cy ? 2 : 0) | (pz >= nd->cz ? 4 : 0);
-}
-
-static int otree_child(OTree* t, int ni, int oct) {
-  if (t->nodes[ni].child[oct] < 0) {
-    float h = t->nodes[ni].half * 0.5f;
-    float cx = t->nodes[ni].cx + ((oct & 1) ? h : -h);
-    float cy = t->nodes[ni].cy + ((oct & 2) ? h : -h);
-    float cz = t->nodes[ni].cz + ((oct & 4) ? h : -h);
-    int c = otree_new(t, cx, cy, cz, h);
-    t->nodes[ni].child[oct] = c;
-  }
-  return t->nodes[ni].child[oct];
-}
-
-#define ORACLE_BH_MAX_DEPTH 40
-
-static void otree_insert(OTree* t, const float* x, const float* y, const float* z, int b) {
-  int ni = 0, depth = 0;
-  for (;;) {
+/* node over sorted range [first, first+count) at `level`; cell = integer cell coords at level */
+static int otree_build(OTree* t, int first, int count, int level) {
+  int ni = otree_new(t);
+  {
     ONode* nd = &t->nodes[ni];
-    if (nd->nbody == 0) { nd->body = b; nd->nbody = 1; return; }
-    if (nd->body >= 0 && depth < ORACLE_BH_MAX_DEPTH) {
-      /* occupied leaf: push the resident down one level */
-      int ob = nd->body;
-      nd->body = -1;
-      int oc = otree_child(t, ni, octant(&t->nodes[ni], x[ob], y[ob], z[ob]));
-      t->nodes[oc].body = ob;
-      t->nodes[oc].nbody = 1;
+    nd->first = first;
+    nd->count = count;
+    /* geometry from the key prefix */
+    uint32_t k = t->key[first];
+    uint32_t ix = 0, iy = 0, iz = 0;
+    for (int b = 0; b < 10; b++) {
+      ix |= ((k >> (3 * b + 2)) & 1u) << b;
+      iy |= ((k >> (3 * b + 1)) & 1u) << b;
+      iz |= ((k >> (3 * b + 0)) & 1u) << b;
     }
-    nd = &t->nodes[ni];
-    nd->nbody++;
-    if (depth >= ORACLE_BH_MAX_DEPTH) return; /* coincident bodies: bucket stays a leaf */
-    ni = otree_child(t, ni, octant(&t->nodes[ni], x[b], y[b], z[b]));
-    depth++;
+    int sh = 10 - level;
+    float h = ldexpf(t->half, -level);
+    nd->half = h;
+    nd->cx = t->lo[0] + ((float)(ix >> sh) + 0.5f) * (2.0f * h);
+    nd->cy = t->lo[1] + ((float)(iy >> sh) + 0.5f) * (2.0f * h);
+    nd->cz = t->lo[2] + ((float)(iz >> sh) + 0.5f) * (2.0f * h);
+    nd->is_leaf = (count <= t->leaf_max) || (level >= t->max_depth);
   }
-}
-
-/* post-order mass/COM; leaves at max depth may hold several bodies ->
- * their monopole is accumulated from `bucket` lists built below. */
-static void otree_com(OTree* t, int ni, const float* x, const float* y, const float* z,
-                      const float* m) {
-  ONode* nd = &t->nodes[ni];
-  int has_child = 0;
+  if (t->nodes[ni].is_leaf) {
+    double mx = 0, my = 0, mz = 0, ms = 0;
+    for (int k = first; k < first + count; k++) {
+      int b = t->order[k];
+      double mb = t->m[b];
+      mx += mb * (double)t->x[b]; my += mb * (double)t->y[b]; mz += mb * (double)t->z[b];
+      ms += mb;
+    }
+    ONode* nd = &t->nodes[ni];
+    nd->mass = ms;
+    if (count == 1) {
+      int b = t->order[first];
+      nd->mx = t->x[b]; nd->my = t->y[b]; nd->mz = t->z[b];
+    } else if (ms > 0) {
+      nd->mx = mx / ms; nd->my = my / ms; nd->mz = mz / ms;
+    } else {
+      nd->mx = nd->cx; nd->my = nd->cy; nd->mz = nd->cz;
+    }
+    return ni;
+  }
+  int shift = 27 - 3 * level;
+  int k = first;
   double mx = 0, my = 0, mz = 0, ms = 0;
-  for (int k = 0; k < 8; k++) {
-    int c = nd->child[k];
-    if (c < 0) continue;
-    has_child = 1;
-    otree_com(t, c, x, y, z, m);
-    nd = &t->nodes[ni];
+  while (k < first + count) {
+    uint32_t oct = (t->key[k] >> shift) & 7u;
+    int e = k;
+    while (e < first + count && ((t->key[e] >> shift) & 7u) == oct) e++;
+    int c = otree_build(t, k, e - k, level + 1);
+    t->nodes[ni].child[oct] = c;
     ONode* cn = &t->nodes[c];
     mx += cn->mx * cn->mass; my += cn->my * cn->mass; mz += cn->mz * cn->mass; ms += cn->mass;
+    k = e;
   }
-  if (!has_child && nd->body >= 0) {
-    int b = nd->body;
-    nd->mx = x[b]; nd->my = y[b]; nd->mz = z[b]; nd->mass = m[b];
-    return;
-  }
+  ONode* nd = &t->nodes[ni];
   nd->mass = ms;
   if (ms > 0) { nd->mx = mx / ms; nd->my = my / ms; nd->mz = mz / ms; }
   else { nd->mx = nd->cx; nd->my = nd->cy; nd->mz = nd->cz; }
+  return ni;
 }
 
+typedef struct { uint32_t key; int idx; } KeyIdx;
+static int cmp_keyidx(const void* a, const void* b) {
+  const KeyIdx* p = (const KeyIdx*)a; const KeyIdx* q = (const KeyIdx*)b;
+  if (p->key != q->key) return p->key < q->key ? -1 : 1;
+  return p->idx < q->idx ? -1 : (p->idx > q->idx ? 1 : 0);
+}
+
+/* Accelerations of the bodies listed in tidx (body indices).  Outputs: root mass, node count,
+ * and optionally the Morton-sorted order (sorted position -> body index, n ints). */
 ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y, const float* z,
                                         const float* m, size_t n_t, const int64_t* tidx,
                                         float* ax, float* ay, float* az, float G, float eps2,
-                                        float theta, double* root_mass, int* node_count) {
-  float bmin[3], bmax[3];
-  oracle_bbox(n, x, y, z, bmin, bmax);
-  float cx = 0.5f * (bmin[0] + bmax[0]), cy = 0.5f * (bmin[1] + bmax[1]),
-        cz = 0.5f * (bmin[2] + bmax[2]);
-  float ext = fmaxf(bmax[0] - bmin[0], fmaxf(bmax[1] - bmin[1], bmax[2] - bmin[2]));
-  float half = 0.5f * ext * 1.0001f + 1e-6f;
-  OTree t = {0};
-  otree_new(&t, cx, cy, cz, half);
-  /* bodies that collide at max depth are chained through `next` */
-  for (size_t b = 0; b < n; b++) otree_insert(&t, x, y, z, (int)b);
-  /* max-depth buckets: nbody>1 with no children and body==-1 cannot be resolved from the
-   * tree alone; rebuild their monopoles by a direct pass */
-  otree_com(&t, 0, x, y, z, m);
-  {
-    /* fix-up for buckets (rare: coincident bodies) */
-    for (int ni = 0; ni < t.count; ni++) {
-      ONode* nd = &t.nodes[ni];
-      int leafish = 1;
-      for (int k = 0; k < 8; k++) if (nd->child[k] >= 0) leafish = 0;
-      if (leafish && nd->nbody > 1) { nd->mass = 0; nd->mx = nd->my = nd->mz = 0; }
-    }
+                                        float theta, int max_depth, int leaf_max,
+                                        double* root_mass, int* node_count, int* order_out) {
+  if (max_depth < 1) max_depth = 1;
+  if (max_depth > 10) max_depth = 10;
+  if (leaf_max < 1) leaf_max = 1;
+  float center[3], half;
+  oracle_bh_root(n, x, y, z, center, &half);
+  OTree t;
+  memset(&t, 0, sizeof(t));
+  t.half = half;
+  for (int a = 0; a < 3; a++) t.lo[a] = center[a] - half;
+  const float scale = 1024.0f / (2.0f * half);
+  KeyIdx* ki = (KeyIdx*)malloc(n * sizeof(KeyIdx));
+  for (size_t i = 0; i < n; i++) {
+    ki[i].key = oracle_bh_key(x[i], y[i], z[i], t.lo, scale);
+    ki[i].idx = (int)i;
   }
+  qsort(ki, n, sizeof(KeyIdx), cmp_keyidx);
+  uint32_t* key = (uint32_t*)malloc(n * sizeof(uint32_t));
+  int* order = (int*)malloc(n * sizeof(int));
+  int* pos_of = (int*)malloc(n * sizeof(int));
+  for (size_t k = 0; k < n; k++) { key[k] = ki[k].key; order[k] = ki[k].idx; pos_of[ki[k].idx] = (int)k; }
+  free(ki);
+  t.key = key; t.order = order; t.x = x; t.y = y; t.z = z; t.m = m;
+  t.max_depth = max_depth; t.leaf_max = leaf_max;
+  otree_build(&t, 0, (int)n, 0);
   if (root_mass) *root_mass = t.nodes[0].mass;
   if (node_count) *node_count = t.count;
+  if (order_out) memcpy(order_out, order, n * sizeof(int));
   const float theta2 = theta * theta;
   const ONode* nodes = t.nodes;
 #pragma omp parallel for schedule(dynamic, 64)
@@ -582,28 +638,38 @@ ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y
     int i = (int)tidx[k];
     float xi = x[i], yi = y[i], zi = z[i];
     double a0 = 0, a1 = 0, a2 = 0;
-    int stack[8 * (ORACLE_BH_MAX_DEPTH + 2)];
+    int stack[8 * 12];
     int sp = 0;
     stack[sp++] = 0;
     while (sp > 0) {
       const ONode* nd = &nodes[stack[--sp]];
-      if (nd->nbody == 0 || nd->mass <= 0) continue;
-      int is_leaf = 1;
-      for (int c = 0; c < 8; c++) if (nd->child[c] >= 0) is_leaf = 0;
-      if (is_leaf && nd->body == i) continue; /* :160-162 self */
+      if (nd->mass == 0.0) continue; /* :161-162 */
+      if (nd->is_leaf) {
+        for (int q = nd->first; q < nd->first + nd->count; q++) {
+          int j = order[q];
+          if (j == i) continue; /* :175 self */
+          float dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+          float dist2 = dx * dx + dy * dy + dz * dz + eps2;
+          float inv = 1.0f / sqrtf(dist2);
+          float f = G * m[j] * (inv * inv * inv);
+          a0 += (double)(f * dx); a1 += (double)(f * dy); a2 += (double)(f * dz);
+        }
+        continue;
+      }
       float dx = (float)nd->mx - xi, dy = (float)nd->my - yi, dz = (float)nd->mz - zi;
       float dist2 = dx * dx + dy * dy + dz * dz + eps2; /* :165 */
-      float size = 2.0f * nd->half;                       /* :168 */
-      if (is_leaf || (size * size) / dist2 < theta2) {    /* :171-172 */
+      float size = 2.0f * nd->half;
+      float size2 = size * size;                         /* :168 */
+      if (size2 / dist2 < theta2) {                      /* :171-172 */
         float inv = 1.0f / sqrtf(dist2);
         float f = G * (float)nd->mass * (inv * inv * inv);
         a0 += (double)(f * dx); a1 += (double)(f * dy); a2 += (double)(f * dz);
       } else {
-        for (int c = 0; c < 8; c++) if (nd->child[c] >= 0) stack[sp++] = nd->child[c];
+        for (int c = 7; c >= 0; c--) if (nd->child[c] >= 0) stack[sp++] = nd->child[c];
       }
     }
     ax[k] = (float)a0; ay[k] = (float)a1; az[k] = (float)a2;
   }
-  free(t.nodes);
+  free(t.nodes); free(key); free(order); free(pos_of);
   return 0;
 }

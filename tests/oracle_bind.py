@@ -52,8 +52,9 @@ class Oracle:
         L.oracle_direct_cutoff_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, C.c_size_t, _i64, _f, _f,
                                                   _f, C.c_float, C.c_float, C.c_float]
         L.oracle_barnes_hut_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, C.c_size_t, _i64, _f, _f, _f,
-                                               C.c_float, C.c_float, C.c_float,
-                                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
+                                               C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                               C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
+        L.oracle_bh_root.argtypes = [C.c_size_t, _f, _f, _f, _f3, C.POINTER(C.c_float)]
         L.oracle_barnes_hut_forces.restype = C.c_int
 
     # -- convenience wrappers (numpy in / numpy out) ------------------------------------------
@@ -138,13 +139,23 @@ class Oracle:
         self.L.oracle_direct_cutoff_forces(x.size, x, y, z, m, idx.size, idx, ax, ay, az, G, eps2, cutoff)
         return ax, ay, az
 
-    def barnes_hut_forces(self, x, y, z, m, idx, G, eps2, theta):
+    def barnes_hut_forces(self, x, y, z, m, idx, G, eps2, theta, max_depth=10, leaf_max=1,
+                          want_order=False):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         ax, ay, az = (np.empty(idx.size, np.float32) for _ in range(3))
         rm, nc = C.c_double(), C.c_int()
+        order = np.empty(x.size, np.int32) if want_order else None
         self.L.oracle_barnes_hut_forces(x.size, x, y, z, m, idx.size, idx, ax, ay, az, G, eps2, theta,
-                                        C.byref(rm), C.byref(nc))
+                                        max_depth, leaf_max, C.byref(rm), C.byref(nc),
+                                        order.ctypes.data if want_order else None)
+        if want_order:
+            return ax, ay, az, rm.value, nc.value, order
         return ax, ay, az, rm.value, nc.value
+
+    def bh_root(self, x, y, z):
+        c, h = _f3(), C.c_float()
+        self.L.oracle_bh_root(x.size, x, y, z, c, C.byref(h))
+        return list(c), h.value
 
 
 def host_state(ic: dict) -> dict:
