@@ -1,0 +1,323 @@
+// facade_device.cpp -- the symbols the reference's src/cuda/*.cu provide, implemented by
+// forwarding to the C ABI (include/nbody_hip.h).  No arithmetic here except the host-side
+// initialisers (which the reference also runs on the host, particle_init.cu:286-376).
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "nbody_facade.hpp"
+#include "nbody_hip.h"
+
+namespace nbody {
+
+namespace {
+
+// Status -> exception, mirroring the reference's conventions (error_handling.hpp:29-136).
+void check(int rc, const char* file, int line) {
+  if (rc == NBODY_HIP_OK) return;
+  const char* msg = nbody_hip_last_error();
+  switch (rc) {
+    case NBODY_HIP_ERR_VALIDATION: throw ValidationException(msg);
+    case NBODY_HIP_ERR_RESOURCE:
+      if (std::strstr(msg, "grid too large")) throw std::runtime_error(msg);  // force_spatial_hash.cu:252-254
+      throw ResourceException(msg, 0, 0);
+    default: throw CudaException(msg, file, line);
+  }
+}
+#define NBODY_CHECK(call) check((call), __FILE__, __LINE__)
+
+nbody_particle_data* raw(ParticleData* p) { return reinterpret_cast<nbody_particle_data*>(p); }
+const nbody_particle_data* raw(const ParticleData* p) { return reinterpret_cast<const nbody_particle_data*>(p); }
+static_assert(sizeof(ParticleData) == sizeof(nbody_particle_data), "ParticleData layout");
+static_assert(sizeof(OctreeNode) == 76, "OctreeNode layout");
+
+}  // namespace
+
+nbody_hip_ctx* facadeContext() {
+  static nbody_hip_ctx* ctx = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] { NBODY_CHECK(nbody_hip_ctx_create(&ctx, 0, nullptr)); });
+  return ctx;
+}
+
+// ---- ParticleDataManager (particle_init.cu:143-283) ------------------------------------------
+void ParticleDataManager::allocateDevice(ParticleData& data, size_t count) {
+  NBODY_CHECK(nbody_hip_particles_alloc(raw(&data), count));
+}
+void ParticleDataManager::freeDevice(ParticleData& data) { NBODY_CHECK(nbody_hip_particles_free(raw(&data))); }
+
+void ParticleDataManager::allocateHost(ParticleData& data, size_t count) {
+  float** f = &data.pos_x;
+  for (int k = 0; k < 13; k++) f[k] = new float[count]();
+  data.count = count;
+}
+void ParticleDataManager::freeHost(ParticleData& data) {
+  float** f = &data.pos_x;
+  for (int k = 0; k < 13; k++) { delete[] f[k]; f[k] = nullptr; }
+  data.count = 0;
+}
+void ParticleDataManager::copyToDevice(ParticleData& d_data, const ParticleData& h_data) {
+  NBODY_CHECK(nbody_hip_ctx_synchronize(facadeContext()));
+  NBODY_CHECK(nbody_hip_particles_upload(raw(&d_data), raw(&h_data)));
+}
+void ParticleDataManager::copyToHost(ParticleData& h_data, const ParticleData& d_data) {
+  NBODY_CHECK(nbody_hip_ctx_synchronize(facadeContext()));
+  NBODY_CHECK(nbody_hip_particles_download(raw(&h_data), raw(&d_data)));
+}
+void ParticleDataManager::copyPositionsToHost(float* x, float* y, float* z, const ParticleData& d) {
+  ParticleData h, dd = d;
+  h.count = d.count;
+  // download() copies ten arrays; positions only need three -> temporary host arrays for the rest
+  std::vector<float> scratch(d.count * 7);
+  h.pos_x = x; h.pos_y = y; h.pos_z = z;
+  float* s = scratch.data();
+  h.vel_x = s; h.vel_y = s + d.count; h.vel_z = s + 2 * d.count; h.acc_x = s + 3 * d.count;
+  h.acc_y = s + 4 * d.count; h.acc_z = s + 5 * d.count; h.mass = s + 6 * d.count;
+  copyToHost(h, dd);
+}
+void ParticleDataManager::copyPositionsToDevice(ParticleData& d, const float* x, const float* y, const float* z) {
+  ParticleData h;
+  allocateHost(h, d.count);
+  copyToHost(h, d);
+  std::copy(x, x + d.count, h.pos_x);
+  std::copy(y, y + d.count, h.pos_y);
+  std::copy(z, z + d.count, h.pos_z);
+  copyToDevice(d, h);
+  freeHost(h);
+}
+
+// ---- ParticleInitializer: the three host recipes of particle_init.cu:286-376 ------------------
+std::mt19937 ParticleInitializer::createRNG(unsigned int seed) { return std::mt19937(seed); }
+
+void ParticleInitializer::zeroVelocities(ParticleData& h) {
+  std::fill_n(h.vel_x, h.count, 0.0f); std::fill_n(h.vel_y, h.count, 0.0f); std::fill_n(h.vel_z, h.count, 0.0f);
+}
+void ParticleInitializer::zeroAccelerations(ParticleData& h) {
+  float* six[] = {h.acc_x, h.acc_y, h.acc_z, h.acc_old_x, h.acc_old_y, h.acc_old_z};
+  for (float* a : six) std::fill_n(a, h.count, 0.0f);
+}
+
+void ParticleInitializer::initUniform(ParticleData& h, const UniformDistParams& p, unsigned int seed) {
+  std::mt19937 rng = createRNG(seed);
+  std::uniform_real_distribution<float> ux(p.min_bounds.x, p.max_bounds.x), uy(p.min_bounds.y, p.max_bounds.y),
+      uz(p.min_bounds.z, p.max_bounds.z), um(p.min_mass, p.max_mass);
+  for (size_t i = 0; i < h.count; i++) {  // draw order per body: x, y, z, mass
+    h.pos_x[i] = ux(rng); h.pos_y[i] = uy(rng); h.pos_z[i] = uz(rng);
+    h.mass[i] = um(rng);
+  }
+  zeroVelocities(h);
+  zeroAccelerations(h);
+}
+
+void ParticleInitializer::initSpherical(ParticleData& h, const SphericalDistParams& p, unsigned int seed) {
+  std::mt19937 rng = createRNG(seed);
+  std::uniform_real_distribution<float> u01(0.0f, 1.0f), um(p.min_mass, p.max_mass);
+  for (size_t i = 0; i < h.count; i++) {  // draw order per body: radius, azimuth, polar, mass
+    const float r = std::cbrt(u01(rng)) * p.radius;        // uniform in volume
+    const float theta = u01(rng) * 2.0f * 3.14159265f;
+    const float phi = std::acos(2.0f * u01(rng) - 1.0f);
+    h.pos_x[i] = p.center.x + r * std::sin(phi) * std::cos(theta);
+    h.pos_y[i] = p.center.y + r * std::sin(phi) * std::sin(theta);
+    h.pos_z[i] = p.center.z + r * std::cos(phi);
+    h.mass[i] = um(rng);
+  }
+  zeroVelocities(h);
+  zeroAccelerations(h);
+}
+
+void ParticleInitializer::initDisk(ParticleData& h, const DiskDistParams& p, unsigned int seed) {
+  std::mt19937 rng = createRNG(seed);
+  std::uniform_real_distribution<float> u01(0.0f, 1.0f), um(p.min_mass, p.max_mass);
+  for (size_t i = 0; i < h.count; i++) {  // draw order per body: radius, azimuth, height, mass
+    const float r = std::sqrt(u01(rng)) * p.radius;
+    const float theta = u01(rng) * 2.0f * 3.14159265f;
+    const float z = (u01(rng) - 0.5f) * p.thickness;
+    h.pos_x[i] = p.center.x + r * std::cos(theta);
+    h.pos_y[i] = p.center.y + r * std::sin(theta);
+    h.pos_z[i] = p.center.z + z;
+    const float v = p.rotation_speed * std::sqrt(r);       // tangential
+    h.vel_x[i] = -v * std::sin(theta);
+    h.vel_y[i] = v * std::cos(theta);
+    h.vel_z[i] = 0.0f;
+    h.mass[i] = um(rng);
+  }
+  zeroAccelerations(h);
+}
+
+// ---- Direct ------------------------------------------------------------------------------------
+void launchDirectForceKernel(ParticleData* d, float G, float eps2, int block_size) {
+  NBODY_CHECK(nbody_hip_direct_forces(facadeContext(), raw(d), G, eps2, block_size));
+}
+DirectForceCalculator::DirectForceCalculator(int block_size) : block_size_(block_size) {}
+void DirectForceCalculator::computeForces(ParticleData* d) {
+  launchDirectForceKernel(d, G_, softening_eps2_, block_size_);
+}
+
+Vec3 computeGravitationalForceCPU(const Vec3& p1, const Vec3& p2, float /*m1*/, float m2, float G, float eps) {
+  // host helper of the reference (force_direct.cu:109-117): acceleration of body 1 due to body 2
+  const Vec3 r = p2 - p1;
+  const float inv = 1.0f / std::sqrt(r.length2() + eps * eps);
+  return r * (G * m2 * (inv * inv * inv));
+}
+
+// ---- Barnes-Hut -----------------------------------------------------------------------------
+BarnesHutTree::BarnesHutTree(size_t max_particles) : max_particles_(max_particles) {
+  NBODY_CHECK(nbody_hip_tree_create(facadeContext(), max_particles, &tree_));
+}
+BarnesHutTree::~BarnesHutTree() { nbody_hip_tree_destroy(tree_); }
+void BarnesHutTree::build(const ParticleData* d) {
+  NBODY_CHECK(nbody_hip_tree_build(tree_, raw(d)));
+  int level_base[12];
+  NBODY_CHECK(nbody_hip_tree_stats(tree_, &node_count_, &root_mass_, nullptr, level_base));
+  max_nodes_ = static_cast<size_t>(node_count_);
+  max_depth_ = 0;
+  for (int l = 1; l < 12; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
+}
+void BarnesHutTree::computeForces(ParticleData* d, float theta, float G, float eps) {
+  NBODY_CHECK(nbody_hip_tree_compute_forces(tree_, raw(d), theta, G, eps));
+}
+void BarnesHutTree::copyNodesToHost() {
+  h_nodes_.resize(static_cast<size_t>(node_count_));
+  NBODY_CHECK(nbody_hip_tree_copy_nodes(tree_, h_nodes_.data(), node_count_, nullptr));
+}
+bool BarnesHutTree::verifyTreeStructure() const { return node_count_ > 0; }
+bool BarnesHutTree::verifyMassConservation(const ParticleData* h) const {
+  float total = 0.0f;
+  for (size_t i = 0; i < h->count; i++) total += h->mass[i];
+  return std::abs(total - root_mass_) < 0.001f * total;
+}
+
+BarnesHutCalculator::BarnesHutCalculator(float theta) : theta_(theta) {}
+BarnesHutCalculator::~BarnesHutCalculator() = default;
+void BarnesHutCalculator::computeForces(ParticleData* d) {
+  if (!tree_) tree_ = std::make_unique<BarnesHutTree>(d->count);
+  tree_->build(d);
+  tree_->computeForces(d, theta_, G_, softening_eps_);
+}
+
+// ---- Spatial hash ----------------------------------------------------------------------------
+SpatialHashGrid::SpatialHashGrid(size_t max_particles, float cell_size)
+    : max_particles_(max_particles), cell_size_(cell_size) {
+  NBODY_CHECK(nbody_hip_grid_create(facadeContext(), max_particles, cell_size, &grid_));
+}
+SpatialHashGrid::~SpatialHashGrid() { nbody_hip_grid_destroy(grid_); }
+void SpatialHashGrid::build(const ParticleData* d) {
+  NBODY_CHECK(nbody_hip_grid_build(grid_, raw(d)));
+  int dims[3];
+  float lo[3], hi[3];
+  NBODY_CHECK(nbody_hip_grid_info(grid_, dims, &total_cells_, lo, hi));
+  grid_dims_ = make_int3(dims[0], dims[1], dims[2]);
+  bbox_min_ = Vec3(lo[0], lo[1], lo[2]);
+  bbox_max_ = Vec3(hi[0], hi[1], hi[2]);
+  built_count_ = d->count;
+}
+void SpatialHashGrid::computeForces(ParticleData* d, float cutoff, float G, float eps) {
+  NBODY_CHECK(nbody_hip_grid_compute_forces(grid_, raw(d), cutoff, G, eps));
+}
+void SpatialHashGrid::copyCellDataToHost(std::vector<int>& cell_start, std::vector<int>& cell_end,
+                                         std::vector<int>& particle_cells, std::vector<int>& sorted_indices) {
+  cell_start.resize(static_cast<size_t>(total_cells_));
+  cell_end.resize(static_cast<size_t>(total_cells_));
+  particle_cells.resize(built_count_);
+  sorted_indices.resize(built_count_);
+  NBODY_CHECK(nbody_hip_grid_copy_cell_data(grid_, cell_start.data(), cell_end.data(), particle_cells.data(),
+                                            sorted_indices.data()));
+}
+int3 SpatialHashGrid::getCellIndex(float x, float y, float z, float cell_size) {
+  return make_int3(static_cast<int>(std::floor(x / cell_size)), static_cast<int>(std::floor(y / cell_size)),
+                   static_cast<int>(std::floor(z / cell_size)));
+}
+int SpatialHashGrid::hashCell(int3 c, int3 g) {
+  const int cx = ((c.x % g.x) + g.x) % g.x, cy = ((c.y % g.y) + g.y) % g.y, cz = ((c.z % g.z) + g.z) % g.z;
+  return cx + cy * g.x + cz * g.x * g.y;
+}
+bool SpatialHashGrid::verifyCellAssignment(const ParticleData* h) const {
+  std::vector<int> pc(built_count_);
+  if (nbody_hip_grid_copy_cell_data(grid_, nullptr, nullptr, pc.data(), nullptr) != NBODY_HIP_OK) return false;
+  for (size_t i = 0; i < h->count && i < built_count_; i++) {
+    int3 c = getCellIndex(h->pos_x[i] - bbox_min_.x, h->pos_y[i] - bbox_min_.y, h->pos_z[i] - bbox_min_.z, cell_size_);
+    c.x = std::max(0, std::min(c.x, grid_dims_.x - 1));
+    c.y = std::max(0, std::min(c.y, grid_dims_.y - 1));
+    c.z = std::max(0, std::min(c.z, grid_dims_.z - 1));
+    if (pc[i] != c.x + c.y * grid_dims_.x + c.z * grid_dims_.x * grid_dims_.y) return false;
+    const float lo[3] = {bbox_min_.x + c.x * cell_size_, bbox_min_.y + c.y * cell_size_, bbox_min_.z + c.z * cell_size_};
+    const float p[3] = {h->pos_x[i], h->pos_y[i], h->pos_z[i]};
+    for (int a = 0; a < 3; a++)
+      if (p[a] < lo[a] || p[a] > lo[a] + cell_size_) return false;
+  }
+  return true;
+}
+
+SpatialHashCalculator::SpatialHashCalculator(float cell_size, float cutoff_radius)
+    : cell_size_(cell_size), cutoff_radius_(cutoff_radius) {}
+SpatialHashCalculator::~SpatialHashCalculator() = default;
+void SpatialHashCalculator::computeForces(ParticleData* d) {
+  if (!grid_) grid_ = std::make_unique<SpatialHashGrid>(d->count, cell_size_);
+  grid_->build(d);
+  grid_->computeForces(d, cutoff_radius_, G_, softening_eps_);
+}
+
+// ---- factory (force_spatial_hash.cu:380-401) -------------------------------------------------
+std::unique_ptr<ForceCalculator> createForceCalculator(ForceMethod method, const SimulationConfig& cfg) {
+  std::unique_ptr<ForceCalculator> calc;
+  switch (method) {
+    case ForceMethod::BARNES_HUT: calc = std::make_unique<BarnesHutCalculator>(cfg.barnes_hut_theta); break;
+    case ForceMethod::SPATIAL_HASH:
+      calc = std::make_unique<SpatialHashCalculator>(cfg.spatial_hash_cell_size, cfg.spatial_hash_cutoff);
+      break;
+    case ForceMethod::DIRECT_N2:
+    default: calc = std::make_unique<DirectForceCalculator>(cfg.cuda_block_size); break;
+  }
+  calc->setGravitationalConstant(cfg.G);
+  calc->setSofteningParameter(cfg.softening);
+  return calc;
+}
+
+// ---- Integrator (integrator.cu:122-293) --------------------------------------------------------
+void launchUpdatePositionsKernel(ParticleData* d, float dt, int) {
+  NBODY_CHECK(nbody_hip_update_positions(facadeContext(), raw(d), dt));
+}
+void launchUpdateVelocitiesKernel(ParticleData* d, float dt, int) {
+  NBODY_CHECK(nbody_hip_update_velocities(facadeContext(), raw(d), dt));
+}
+void launchStoreAccelerationsKernel(ParticleData* d, int) {
+  NBODY_CHECK(nbody_hip_store_accelerations(facadeContext(), raw(d)));
+}
+float launchComputeKineticEnergyKernel(const ParticleData* d, int) {
+  float e = 0.f;
+  NBODY_CHECK(nbody_hip_kinetic_energy(facadeContext(), raw(d), &e));
+  return e;
+}
+float launchComputePotentialEnergyKernel(const ParticleData* d, float G, float eps, int) {
+  float e = 0.f;
+  NBODY_CHECK(nbody_hip_potential_energy(facadeContext(), raw(d), G, eps, &e));
+  return e;
+}
+
+Integrator::Integrator(int block_size) : block_size_(block_size) {}
+Integrator::~Integrator() = default;
+void Integrator::ensureScratchBuffer(size_t) {}
+void Integrator::integrate(ParticleData* d, ForceCalculator* fc, float dt) {
+  if (fc->getMethod() == ForceMethod::DIRECT_N2 && dynamic_cast<DirectForceCalculator*>(fc)) {
+    // fused drift + force + kick (same result as the four calls below)
+    const float eps = fc->getSofteningParameter();
+    NBODY_CHECK(nbody_hip_integrate_direct(facadeContext(), raw(d), fc->getGravitationalConstant(), eps * eps, dt, 1));
+    return;
+  }
+  storeOldAccelerations(d);
+  updatePositions(d, dt);
+  fc->computeForces(d);
+  updateVelocities(d, dt);
+}
+void Integrator::updatePositions(ParticleData* d, float dt) { launchUpdatePositionsKernel(d, dt, block_size_); }
+void Integrator::updateVelocities(ParticleData* d, float dt) { launchUpdateVelocitiesKernel(d, dt, block_size_); }
+void Integrator::storeOldAccelerations(ParticleData* d) { launchStoreAccelerationsKernel(d, block_size_); }
+float Integrator::computeKineticEnergy(const ParticleData* d) { return launchComputeKineticEnergyKernel(d, block_size_); }
+float Integrator::computePotentialEnergy(const ParticleData* d, float G, float eps) {
+  return launchComputePotentialEnergyKernel(d, G, eps, block_size_);
+}
+float Integrator::computeTotalEnergy(const ParticleData* d, float G, float eps) {
+  return computeKineticEnergy(d) + computePotentialEnergy(d, G, eps);
+}
+
+}  // namespace nbody

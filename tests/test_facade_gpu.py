@@ -1,0 +1,62 @@
+"""The C++ facade (compiled-language host side over the C ABI) on a real GPU:
+  * n-body_amd/lib/facade_tests      the reference's hot-path gtest cases on a mini harness
+  * oracle/_ref/example_*            the reference's OWN, unmodified example programs and
+                                     ParticleSystem (compiled from /root/reference by
+                                     oracle/Makefile.ref in the build container) linked against
+                                     libnbody_facade.so -- the drop-in proof.  /root/reference is
+                                     not read at run time; the binaries travel with the snapshot.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "n-body_amd", "lib")
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _run(exe, cwd, timeout=600):
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIB + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    return subprocess.run([exe], cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_facade_reference_cases():
+    exe = os.path.join(LIB, "facade_tests")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    r = _run(exe, ROOT)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 failed" in r.stdout
+
+
+def _need(name):
+    exe = os.path.join(REF, name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (needs /root/reference at build time)")
+    return exe
+
+
+# examples/example_energy_conservation.cpp, unmodified: E0 ~ -0.25, "excellent" (< 0.1 %) drift
+def test_reference_example_energy_conservation(tmp_path):
+    r = _run(_need("example_energy_conservation"), str(tmp_path))
+    out = r.stdout
+    assert r.returncode == 0, out[-2000:] + r.stderr[-2000:]
+    e0 = float(re.search(r"Initial Energy:\s+(-?[\d.eE+-]+)", out).group(1))
+    drift = float(re.search(r"Max Drift:\s+([\d.eE+-]+)%", out).group(1))
+    assert abs(e0 - (-0.25)) < 1e-3
+    assert drift < 0.1 and "Excellent energy conservation" in out
+    assert (tmp_path / "energy_data.csv").exists()
+
+
+# examples/example_force_methods.cpp, unmodified: ParticleSystem::initialize / setForceMethod /
+# getState / setState / update over all three strategies and four sizes
+def test_reference_example_force_methods(tmp_path):
+    r = _run(_need("example_force_methods"), str(tmp_path))
+    out = r.stdout
+    assert r.returncode == 0, out[-2000:] + r.stderr[-2000:]
+    for name in ("Direct N", "Barnes-Hut", "Spatial Hash", "Performance Scaling", "20000"):
+        assert name in out
