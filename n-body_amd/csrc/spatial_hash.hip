@@ -41,10 +41,13 @@ __global__ void bbox_init_kernel(unsigned int* enc) {
   else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;           // maxs
 }
 
-// min/max of x,y,z: wave64 shuffle reduce, one atomic per wave on order-preserving integers
-// (the reference CAS-loops float atomics from every block, force_barnes_hut.cu:41-110)
+// min/max of x,y,z: wave64 shuffle reduce -> LDS across the block's 4 waves -> 6 atomics per
+// BLOCK on order-preserving integers, from at most 256 blocks (1,536 atomics in all: every wave
+// hitting the same six words serialises at ~11 ns each, measured 282 us with 24,576 of them).
+// The reference CAS-loops float atomics from every block (force_barnes_hut.cu:41-110).
 __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__ posm, int n,
                                                       unsigned int* __restrict__ enc) {
+  __shared__ float red[4][6];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 p = posm[i];
@@ -60,19 +63,25 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
       hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
     }
   }
+  const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&enc[a], float_to_ordered(lo[a]));
-      atomicMax(&enc[3 + a], float_to_ordered(hi[a]));
-    }
+    for (int a = 0; a < 3; a++) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int k = 1; k < 4; k++) v = a < 3 ? fminf(v, red[k][a]) : fmaxf(v, red[k][a]);
+    if (a < 3) atomicMin(&enc[a], float_to_ordered(v));
+    else atomicMax(&enc[a], float_to_ordered(v));
   }
 }
 
 int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc) {
   const int blocks = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
-  hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(kBlock), 0, ctx->stream,
+  hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream,
                      posm, n, enc);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
@@ -158,61 +167,76 @@ __device__ __forceinline__ int lower_bound_keys(const unsigned int* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// Force kernel.  grid = (ceil(gx / W), gy, gz); block = 256.
+// Force kernel.  grid = (ceil(gx / (4 Wv)), gy, gz); block = 256 = 4 waves.
+// Wave w owns the run of Wv cells [x0 + w Wv, +Wv) of row (y, z): its targets are one contiguous
+// range (about 64 bodies: Wv = 64 / mean occupancy).  The block streams, row by row (9 rows:
+// y+-1, z+-1), the sources of cells [x0-1, x0+4Wv] through LDS tiles; each wave only visits the
+// part of a tile that lies in ITS cells [xw-1, xw+Wv], so a target tests 9 (Wv+2) rho candidates
+// (2x the 27-cell minimum at Wv = 4) with all lanes busy.  All range ends come from one batch of
+// binary searches in the sorted key array (9 rows x (4Wv+3) cell boundaries, one per lane).
 // GUARD : eps2 so small that m*rsq(eps2)^3 may overflow -> d2 > 0 tested explicitly
 // STRICT: cutoff > cell_size -> only x-adjacent cells interact (the reference's 27-cell search)
 // ---------------------------------------------------------------------------------------
+constexpr int kMaxWv = 16;
+constexpr int kMaxBW = 4 * kMaxWv;
+
 template <bool GUARD, bool STRICT>
 __global__ __launch_bounds__(kBlock) void hash_force_kernel(
     const float4* __restrict__ sorted, const unsigned int* __restrict__ keys,
-    const int* __restrict__ idx, int n, const GridInfo* __restrict__ info, int W, float cutoff2,
+    const int* __restrict__ idx, int n, const GridInfo* __restrict__ info, int Wv, float cutoff2,
     float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
     float* __restrict__ acc_z) {
-  __shared__ int range[20];  // [0,1] targets; [2+2r, 3+2r] source row r (0..8)
+  __shared__ int rowpos[9][kMaxBW + 3];  // sorted position of the first body of cell x0-1+j
+  __shared__ int tpos[5];                // target range boundaries of the 4 waves
   __shared__ float4 tile[2][HTS];
   __shared__ int tile_cx[2][HTS];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int gx = info->dims[0], gy = info->dims[1], gz = info->dims[2];
-  const int x0 = blockIdx.x * W, y = blockIdx.y, z = blockIdx.z;
-  const int x1 = min(x0 + W, gx);
+  const int BW = 4 * Wv;
+  const int x0 = blockIdx.x * BW, y = blockIdx.y, z = blockIdx.z;
 
-  if (tid < 20) {
-    int r = -1;  // -1: targets
-    int which = tid & 1;
-    if (tid >= 2) r = (tid - 2) >> 1;
+  // cell boundaries: thread (r, j) -> lower_bound of cell (x0-1+j) in row r
+  for (int q = tid; q < 9 * (BW + 3); q += kBlock) {
+    const int r = q / (BW + 3), j = q - r * (BW + 3);
+    const int yy = y + (r % 3) - 1, zz = z + (r / 3) - 1;
     int val = 0;
-    if (r < 0) {
-      const unsigned int base = (unsigned int)((z * gy + y) * gx);
-      val = lower_bound_keys(keys, n, base + (unsigned int)(which ? x1 : x0));
-    } else {
-      const int yy = y + (r % 3) - 1, zz = z + (r / 3) - 1;
-      if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
-        const unsigned int base = (unsigned int)((zz * gy + yy) * gx);
-        const int xa = max(x0 - 1, 0), xb = min(x1 + 1, gx);
-        val = lower_bound_keys(keys, n, base + (unsigned int)(which ? xb : xa));
-      }
+    if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+      const unsigned int base = (unsigned int)((zz * gy + yy) * gx);
+      const int cx = min(max(x0 - 1 + j, 0), gx);  // clamp to the row: [0, gx]
+      val = lower_bound_keys(keys, n, base + (unsigned int)cx);
     }
-    range[tid] = val;
+    rowpos[r][j] = val;
   }
   __syncthreads();
-  const int t0 = range[0], t1 = range[1];
-  if (t0 >= t1) return;  // empty run (uniform over the block)
+  // own row is r = 4 (dy = dz = 0); wave w's targets start at cell x0 + w Wv = boundary 1 + w Wv
+  if (tid < 5) tpos[tid] = rowpos[4][min(1 + tid * Wv, BW + 2)];
+  __syncthreads();
+  const int bt0 = tpos[0], bt1 = tpos[4];
+  if (bt0 >= bt1) return;  // no targets in this block (uniform)
+  const int t0 = tpos[w], t1 = tpos[w + 1];
+  int maxcnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) maxcnt = max(maxcnt, tpos[k + 1] - tpos[k]);
+  const int nchunks = (maxcnt + 63) / 64;  // uniform over the block
 
   int tc = 0;  // running tile counter: buffer = tc & 1, ONE barrier per tile (the other buffer is
                // only rewritten after the next barrier, when every wave has left it)
-  for (int tb = t0; tb < t1; tb += kBlock) {
-    const int t = tb + tid;
+  for (int ch = 0; ch < nchunks; ch++) {
+    const int t = t0 + ch * 64 + lane;
+    const bool wave_active = t0 + ch * 64 < t1;  // wave-uniform
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     int cxi = 0;
     if (t < t1) {
       pi = sorted[t];
       if (STRICT) cxi = (int)(keys[t] % (unsigned int)gx);
     }
-    // fp32 sums of 64 sources folded into fp64: a dense cell neighbourhood is thousands of terms
-    // with heavy cancellation (uniform interior); long fp32 running sums would cost digits
+    // fp32 sums of <= 64 sources folded into fp64: a dense cell neighbourhood is thousands of
+    // terms with heavy cancellation (uniform interior); long fp32 running sums would cost digits
     double sx = 0.0, sy = 0.0, sz = 0.0;
     for (int r = 0; r < 9; r++) {
-      const int s0 = range[2 + 2 * r], s1 = range[3 + 2 * r];
+      const int s0 = rowpos[r][0], s1 = rowpos[r][BW + 2];
+      // this wave's part of the row: cells [xw-1, xw+Wv]
+      const int ws0 = rowpos[r][w * Wv], ws1 = rowpos[r][min(w * Wv + Wv + 2, BW + 2)];
       for (int jb = s0; jb < s1; jb += HTS, tc++) {
         const int b = tc & 1;
         const int j = jb + tid;
@@ -221,10 +245,11 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
           if (STRICT) tile_cx[b][tid] = (int)(keys[j] % (unsigned int)gx);
         }
         __syncthreads();
-        const int cnt = min(HTS, s1 - jb);
-        for (int kb = 0; kb < cnt; kb += 64) {  // fold every 64 sources: see comment above
+        const int k0 = wave_active ? max(ws0, jb) - jb : 0;
+        const int k1 = wave_active ? min(ws1, min(s1, jb + HTS)) - jb : 0;
+        for (int kb = k0; kb < k1; kb += 64) {
           float ax = 0.f, ay = 0.f, az = 0.f;
-          const int ke = min(kb + 64, cnt);
+          const int ke = min(kb + 64, k1);
 #pragma unroll 4
           for (int k = kb; k < ke; k++) {
             const float4 s = tile[b][k];
@@ -406,13 +431,12 @@ extern "C" int nbody_hip_grid_compute_forces(nbody_hip_grid* g, nbody_particle_d
   NBH_HIP(hipSetDevice(ctx->device));
   const int n = (int)g->built_count;
   const int gx = g->info.dims[0], gy = g->info.dims[1], gz = g->info.dims[2];
-  // run width: aim for ~128 targets per workgroup at the mean occupancy
+  // cells per wave: ~64 targets per wave at the mean occupancy
   const double rho = (double)n / (double)g->info.total;
-  int W = rho > 0 ? (int)(128.0 / rho + 0.5) : gx;
+  int W = rho > 0 ? (int)(64.0 / rho + 0.5) : kMaxWv;
   if (W < 1) W = 1;
-  if (W > gx) W = gx;
-  if (W > 64) W = 64;
-  const dim3 grid((gx + W - 1) / W, gy, gz);
+  if (W > kMaxWv) W = kMaxWv;
+  const dim3 grid((gx + 4 * W - 1) / (4 * W), gy, gz);
   if (grid.y > 65535u || grid.z > 65535u)
     return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;  // :312-313
