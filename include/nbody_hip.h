@@ -199,6 +199,23 @@ NBODY_HIP_API int nbody_hip_grid_info(const nbody_hip_grid* grid, int dims[3], i
 NBODY_HIP_API int nbody_hip_grid_copy_cell_data(nbody_hip_grid* grid, int* cell_start, int* cell_end,
                                                 int* particle_cells, int* sorted_indices);
 
+/* Packed forms used by the sharded (multi-GPU, z-slab) spatial-hash path.  `bounds` = {lo x,y,z,
+ * hi x,y,z} of the ALREADY PADDED global box (NULL: box of these bodies padded by 0.001), so that
+ * every rank bins on the same grid; acc_out[i] = {ax, ay, az, 0} for every body of the last build,
+ * in its input order (a rank passes [own bodies; halo bodies] and keeps the first part). */
+NBODY_HIP_API int nbody_hip_grid_build_packed(nbody_hip_grid* grid, const nbody_float4* posm, size_t count,
+                                              const float* bounds);
+NBODY_HIP_API int nbody_hip_grid_compute_forces_packed(nbody_hip_grid* grid, float cutoff, float G, float eps,
+                                                       nbody_float4* acc_out);
+/* min/max of packed bodies into a DEVICE array of 6 floats {lo x,y,z, hi x,y,z} (async; the ranks
+ * all-reduce it).  ref: computeBoundingBoxKernel, force_barnes_hut.cu:66-110 */
+NBODY_HIP_API int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t count,
+                                        float* bounds_device);
+/* z cell coordinate (clamped to [0, gz-1]) of packed bodies on a grid with origin lo_z; DEVICE
+ * int output.  ref: assignCellsKernel, force_spatial_hash.cu:28-49 */
+NBODY_HIP_API int nbody_hip_cell_z_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t count,
+                                          float lo_z, float cell_size, int gz, int* cz_device);
+
 /* ---- a8: Barnes-Hut (ref: BarnesHutTree / BarnesHutCalculator,
  *          src/cuda/force_barnes_hut.cu:204-532, include/nbody/barnes_hut_tree.hpp:9-81) ---- */
 

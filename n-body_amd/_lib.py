@@ -87,6 +87,10 @@ PROTOTYPES = {
     "nbody_hip_grid_info": (C.c_int, [_P, C.POINTER(C.c_int * 3), C.POINTER(C.c_int),
                                       C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
     "nbody_hip_grid_copy_cell_data": (C.c_int, [_P, _P, _P, _P, _P]),
+    "nbody_hip_grid_build_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "nbody_hip_grid_compute_forces_packed": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
+    "nbody_hip_bbox_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "nbody_hip_cell_z_packed": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_int, _P]),
     "nbody_hip_tree_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nbody_hip_tree_destroy": (C.c_int, [_P]),
     "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
     const float4* __restrict__ sorted, const unsigned int* __restrict__ keys,
     const int* __restrict__ idx, int n, const GridInfo* __restrict__ info, int Wv, float cutoff2,
     float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
-    float* __restrict__ acc_z) {
+    float* __restrict__ acc_z, float4* __restrict__ acc4) {
   __shared__ int rowpos[9][kMaxBW + 3];  // sorted position of the first body of cell x0-1+j
   __shared__ int tpos[5];                // target range boundaries of the 4 waves
   __shared__ float4 tile[2][HTS];
@@ -270,11 +270,26 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
     }
     if (t < t1) {
       const int i = idx[t];
-      acc_x[i] = (float)((double)G * sx);
-      acc_y[i] = (float)((double)G * sy);
-      acc_z[i] = (float)((double)G * sz);
+      const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
+      if (acc4) {
+        acc4[i] = make_float4(fx, fy, fz, 0.f);
+      } else {
+        acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
+      }
     }
   }
+}
+
+// z cell coordinate of every body on a given grid (slab assignment of the sharded path)
+__global__ __launch_bounds__(kBlock) void cell_z_kernel(const float4* __restrict__ posm, int n,
+                                                        float lo_z, float cell, int gz,
+                                                        int* __restrict__ cz) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) cz[i] = cell_coord(posm[i].z, lo_z, cell, gz);
+}
+
+__global__ void bbox_decode_kernel(const unsigned int* __restrict__ enc, float* __restrict__ out) {
+  if (threadIdx.x < 6) out[threadIdx.x] = ordered_to_float(enc[threadIdx.x]);
 }
 
 }  // namespace nbh
@@ -368,42 +383,50 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
   return NBODY_HIP_OK;
 }
 
+
 static int bits_for(long long total) {
   int b = 1;
   while ((1LL << b) < total && b < 32) b++;
   return b;
 }
 
-extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data* d) {
-  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
-  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
-  const size_t n = d->count;
-  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
-  if (n > g->max_particles)
-    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the grid's capacity %zu "
-                    "(sized from the first count seen, ref: force_spatial_hash.cu:372-374)", n, g->max_particles);
-  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass)
-    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+// bounds == nullptr: bounding box of the bodies padded by 0.001 (the reference's build);
+// otherwise {lo x,y,z, hi x,y,z} is used as the (already padded) box -- the sharded path passes
+// the GLOBAL box so that every rank bins on the same grid.
+static int grid_build_packed(nbody_hip_grid* g, const float4* posm, size_t n, const float* bounds) {
   nbody_hip_ctx* ctx = g->ctx;
-  NBH_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
-  float4* posm = static_cast<float4*>(ctx->posm.ptr);
-  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
-
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
-  if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
-  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info);
-  NBH_LAUNCH_CHECK();
-  // the one host round trip of the build: the grid size decides validity (and, for the
-  // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
-  NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
-  NBH_HIP(hipStreamSynchronize(st));
-  g->info = *g->h_info;
-  if (g->info.total > 100000000LL)  // :252-254
-    return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
-
+  if (bounds) {
+    GridInfo& gi = *g->h_info;
+    NBH_HIP(hipStreamSynchronize(st));  // h_info may still be in flight from the previous build
+    long long total = 1;
+    for (int a = 0; a < 3; a++) {
+      gi.bmin[a] = bounds[a];
+      gi.bmax[a] = bounds[3 + a];
+      const float cells = ceilf((bounds[3 + a] - bounds[a]) / g->cell_size);  // :244-246
+      gi.dims[a] = (cells < 1.0e9f && cells >= 0.0f) ? (int)cells + 1 : 0x40000000;
+      total *= gi.dims[a];
+      if (total > 0x4000000000000LL) total = 0x4000000000000LL;
+    }
+    gi.total = total;
+    g->info = gi;
+    if (g->info.total > 100000000LL)
+      return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
+    NBH_HIP(hipMemcpyAsync(g->d_info, g->h_info, sizeof(GridInfo), hipMemcpyHostToDevice, st));
+  } else {
+    if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+    hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info);
+    NBH_LAUNCH_CHECK();
+    // the one host round trip of the build: the grid size decides validity (and, for the
+    // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
+    NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
+    NBH_HIP(hipStreamSynchronize(st));
+    g->info = *g->h_info;
+    if (g->info.total > 100000000LL)  // :252-254
+      return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
+  }
   hipLaunchKernelGGL(assign_cells_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_info,
                      g->cell_size, g->d_keys_a, g->d_idx_a);
   NBH_LAUNCH_CHECK();
@@ -418,13 +441,41 @@ extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data
   return NBODY_HIP_OK;
 }
 
-extern "C" int nbody_hip_grid_compute_forces(nbody_hip_grid* g, nbody_particle_data* d, float cutoff,
-                                             float G, float eps) {
+extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data* d) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
   if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
-  if (g->built_count == 0 || g->built_count != d->count)
-    return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid was not built for this particle set");
-  if (!d->acc_x || !d->acc_y || !d->acc_z) return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  const size_t n = d->count;
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the grid's capacity %zu "
+                    "(sized from the first count seen, ref: force_spatial_hash.cu:372-374)", n, g->max_particles);
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
+  return grid_build_packed(g, posm, n, nullptr);
+}
+
+extern "C" int nbody_hip_grid_build_packed(nbody_hip_grid* g, const nbody_float4* posm, size_t n,
+                                           const float* bounds) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!posm) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the grid's capacity %zu", n, g->max_particles);
+  if (bounds)
+    for (int a = 0; a < 3; a++)
+      if (!(bounds[3 + a] >= bounds[a]) || !(bounds[3 + a] - bounds[a] < INFINITY))
+        return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "invalid grid bounds");
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  return grid_build_packed(g, reinterpret_cast<const float4*>(posm), n, bounds);
+}
+
+static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float eps, float* ax,
+                              float* ay, float* az, float4* acc4) {
   if (!(cutoff > 0.0f) || !(cutoff < INFINITY))
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Spatial hash cutoff must be positive and finite");
   nbody_hip_ctx* ctx = g->ctx;
@@ -444,11 +495,55 @@ extern "C" int nbody_hip_grid_compute_forces(nbody_hip_grid* g, nbody_particle_d
   const bool strict = cutoff > g->cell_size;
 #define NBH_HASH_LAUNCH(GD, ST)                                                                   \
   hipLaunchKernelGGL((hash_force_kernel<GD, ST>), grid, dim3(kBlock), 0, ctx->stream, g->d_sorted, \
-                     g->d_keys_b, g->d_idx_b, n, g->d_info, W, cutoff2, eps2, G, d->acc_x,        \
-                     d->acc_y, d->acc_z)
+                     g->d_keys_b, g->d_idx_b, n, g->d_info, W, cutoff2, eps2, G, ax, ay, az, acc4)
   if (guard) { if (strict) NBH_HASH_LAUNCH(true, true); else NBH_HASH_LAUNCH(true, false); }
   else       { if (strict) NBH_HASH_LAUNCH(false, true); else NBH_HASH_LAUNCH(false, false); }
 #undef NBH_HASH_LAUNCH
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_compute_forces(nbody_hip_grid* g, nbody_particle_data* d, float cutoff,
+                                             float G, float eps) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (g->built_count == 0 || g->built_count != d->count)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid was not built for this particle set");
+  if (!d->acc_x || !d->acc_y || !d->acc_z) return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  return grid_forces_common(g, cutoff, G, eps, d->acc_x, d->acc_y, d->acc_z, nullptr);
+}
+
+extern "C" int nbody_hip_grid_compute_forces_packed(nbody_hip_grid* g, float cutoff, float G, float eps,
+                                                    nbody_float4* acc_out) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!acc_out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid has not been built");
+  return grid_forces_common(g, cutoff, G, eps, nullptr, nullptr, nullptr, reinterpret_cast<float4*>(acc_out));
+}
+
+extern "C" int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t n,
+                                     float* bounds_device) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (!posm || !bounds_device) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (n == 0 || n > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count out of range");
+  NBH_HIP(hipSetDevice(ctx->device));
+  if (int rc = ctx->reduce.reserve(64)) return rc;
+  unsigned int* enc = static_cast<unsigned int*>(ctx->reduce.ptr);
+  if (int rc = launch_bbox(ctx, reinterpret_cast<const float4*>(posm), (int)n, enc)) return rc;
+  hipLaunchKernelGGL(bbox_decode_kernel, dim3(1), dim3(64), 0, ctx->stream, enc, bounds_device);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_cell_z_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t n, float lo_z,
+                                       float cell_size, int gz, int* cz_device) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (n == 0) return NBODY_HIP_OK;
+  if (!posm || !cz_device) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (!(cell_size > 0.0f) || gz < 1) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "invalid grid");
+  NBH_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(cell_z_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                     reinterpret_cast<const float4*>(posm), (int)n, lo_z, cell_size, gz, cz_device);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }

@@ -47,6 +47,37 @@ class HipBackend:
     def forces(self, targets, sources, G, eps2, out, accumulate):
         direct_forces_packed(self.ctx, targets, sources, G, eps2, out=out, accumulate=accumulate)
 
+    # -- spatial hash (z-slab path) ------------------------------------------------------------
+    def bbox(self, posm):
+        """{lo x,y,z, hi x,y,z} of packed bodies as a device tensor of 6 floats."""
+        out = torch.empty(6, dtype=torch.float32, device=posm.device)
+        check(self.ctx._lib.nbody_hip_bbox_packed(self.ctx.handle, posm.data_ptr(), posm.shape[0],
+                                                  out.data_ptr()))
+        return out
+
+    def cell_z(self, posm, lo_z, cell, gz):
+        cz = torch.empty(posm.shape[0], dtype=torch.int32, device=posm.device)
+        check(self.ctx._lib.nbody_hip_cell_z_packed(self.ctx.handle, posm.data_ptr(), posm.shape[0],
+                                                    lo_z, cell, gz, cz.data_ptr()))
+        return cz
+
+    def hash_forces(self, posm_all, bounds, cell, cutoff, G, eps):
+        """Accelerations [n,4] of every body of posm_all on the grid with the given padded bounds."""
+        n = posm_all.shape[0]
+        if getattr(self, "_grid_cap", 0) < n or getattr(self, "_grid_cell", None) != cell:
+            if getattr(self, "_grid", None) is not None:
+                self.ctx._lib.nbody_hip_grid_destroy(self._grid)
+            h = C.c_void_p()
+            cap = int(n * 1.5) + 1024
+            check(self.ctx._lib.nbody_hip_grid_create(self.ctx.handle, cap, cell, C.byref(h)))
+            self._grid, self._grid_cap, self._grid_cell = h, cap, cell
+        b = (C.c_float * 6)(*bounds)
+        check(self.ctx._lib.nbody_hip_grid_build_packed(self._grid, posm_all.data_ptr(), n, b))
+        acc = torch.empty((n, 4), dtype=torch.float32, device=posm_all.device)
+        check(self.ctx._lib.nbody_hip_grid_compute_forces_packed(self._grid, cutoff, G, eps,
+                                                                 acc.data_ptr()))
+        return acc
+
 
 def shard_bounds(n: int, world: int, rank: int):
     """(shard size S, lo, hi) of `rank`: contiguous, every shard padded to S = ceil(n/world)."""
@@ -136,3 +167,174 @@ class ShardedDirectSystem:
         if self.world > 1:
             dist.all_reduce(ke, group=self.group)
         return float(ke.item())
+
+
+def layer_owner(gz: int, world: int) -> np.ndarray:
+    """Owner rank of every z layer of the grid: contiguous slabs, rank r owns layers
+    [r gz // world, (r+1) gz // world) (ranks may own none when gz < world)."""
+    edges = [(r * gz) // world for r in range(world + 1)]
+    owner = np.empty(gz, dtype=np.int64)
+    for r in range(world):
+        owner[edges[r]:edges[r + 1]] = r
+    return owner
+
+
+class ShardedHashSystem:
+    """Spatial hash sharded by z-slabs of cells: the linear cell id
+    x + y gx + z gx gy (force_spatial_hash.cu:48) makes a range of z layers a contiguous block of
+    the cell-ordered body list, so rank r owns the bodies of its layers.  Per force evaluation:
+
+        global box    local min/max (HIP) -> all-reduce MIN/MAX of 6 floats -> every rank bins on
+                      the SAME grid (box padded by 0.001, dims = ceil(extent/cell)+1, like the
+                      reference's build, force_spatial_hash.cu:225-246)
+        migration     bodies whose layer now belongs to another rank move there (all-to-all of
+                      {x,y,z,m}, velocity, previous acceleration: 48 B/body, few bodies per step)
+        halo          the bodies of a rank's lowest / highest layer are sent to the owner of the
+                      layer below / above (16 B/body: one cell layer per direction)
+        forces        27-cell kernel on [own bodies; halo bodies]; only the own part is kept
+
+    One Velocity-Verlet step = drift, the above, kick (ref: Integrator::integrate)."""
+
+    def __init__(self, ic: dict, G: float, eps: float, cell_size: float, cutoff: float,
+                 backend=None, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = backend
+        self.device = torch.device(device) if device is not None else backend.device
+        self.G, self.eps = float(G), float(eps)
+        self.cell, self.cutoff = float(cell_size), float(cutoff)
+        n = int(ic["pos_x"].size)
+        self.n = n
+        # initial ownership: every rank evaluates the same global grid on the host
+        lo, hi, dims = self._grid_from_bounds(
+            [float(ic[k].min()) for k in ("pos_x", "pos_y", "pos_z")] +
+            [float(ic[k].max()) for k in ("pos_x", "pos_y", "pos_z")])
+        cz = np.clip(np.floor((ic["pos_z"] - np.float32(lo[2])) / np.float32(self.cell)).astype(np.int64),
+                     0, dims[2] - 1)
+        mine = np.nonzero(layer_owner(dims[2], self.world)[cz] == self.rank)[0]
+        posm = np.stack([ic["pos_x"][mine], ic["pos_y"][mine], ic["pos_z"][mine], ic["mass"][mine]], 1)
+        vel = np.zeros((mine.size, 4), np.float32)
+        for k, f in enumerate(("vel_x", "vel_y", "vel_z")):
+            if f in ic:
+                vel[:, k] = ic[f][mine]
+        dev = self.device
+        self.posm = torch.from_numpy(np.ascontiguousarray(posm.astype(np.float32))).to(dev)
+        self.vel = torch.from_numpy(vel).to(dev)
+        self.acc = torch.zeros((mine.size, 4), dtype=torch.float32, device=dev)
+        self.gid = torch.from_numpy(mine.astype(np.int64)).to(dev)  # global ids (verification only)
+        self.halo_bodies = 0
+        self.migrated = 0
+
+    # -- grid --------------------------------------------------------------------------------
+    def _grid_from_bounds(self, raw6):
+        f = np.float32
+        lo = [f(raw6[a]) - f(0.001) for a in range(3)]   # force_spatial_hash.cu:225-231
+        hi = [f(raw6[3 + a]) + f(0.001) for a in range(3)]
+        dims = [int(np.ceil((hi[a] - lo[a]) / f(self.cell))) + 1 for a in range(3)]  # :244-246
+        return [float(v) for v in lo], [float(v) for v in hi], dims
+
+    def _global_grid(self):
+        b = self.backend.bbox(self.posm) if self.posm.shape[0] > 0 else torch.tensor(
+            [3e38] * 3 + [-3e38] * 3, dtype=torch.float32, device=self.device)
+        if self.world > 1:
+            lo, hi = b[:3].clone(), b[3:].clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            b = torch.cat([lo, hi])
+        return self._grid_from_bounds(b.cpu().numpy().tolist())
+
+    # -- variable-size exchange: rows of `tensors` selected by `dest` go to their rank -----------
+    def _exchange(self, tensors, dest):
+        W = self.world
+        order = torch.argsort(dest, stable=True)
+        counts = torch.bincount(dest, minlength=W).to(torch.int64)
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=self.group)
+        send_split, recv_split = counts.tolist(), recv_counts.tolist()
+        out = []
+        for t in tensors:
+            src = t.index_select(0, order).contiguous()
+            dst = torch.empty((sum(recv_split),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_to_all_single(dst, src, output_split_sizes=recv_split,
+                                   input_split_sizes=send_split, group=self.group)
+            out.append(dst)
+        return out
+
+    def compute_forces(self):
+        b = self.backend
+        lo, hi, dims = self._global_grid()
+        gz = dims[2]
+        owner_np = layer_owner(gz, self.world)
+        cz = b.cell_z(self.posm, lo[2], self.cell, gz).to(torch.int64) if self.posm.shape[0] else \
+            torch.empty(0, dtype=torch.int64, device=self.device)
+        halo = None
+        if self.world > 1:
+            owner = torch.from_numpy(owner_np).to(self.device)
+            dest = owner[cz]
+            self.migrated = int((dest != self.rank).sum().item())
+            # every rank takes part in the exchange even when nothing moves
+            self.posm, self.vel, self.acc, self.gid, cz = self._exchange(
+                [self.posm, self.vel, self.acc, self.gid, cz], dest)
+            mine = np.nonzero(owner_np == self.rank)[0]
+            send_rows, send_dest = [], []
+            if mine.size:
+                z_lo, z_hi = int(mine[0]), int(mine[-1]) + 1
+                if z_lo > 0:
+                    rows = torch.nonzero(cz == z_lo).flatten()
+                    send_rows.append(rows)
+                    send_dest.append(torch.full_like(rows, int(owner_np[z_lo - 1])))
+                if z_hi < gz:
+                    rows = torch.nonzero(cz == z_hi - 1).flatten()
+                    send_rows.append(rows)
+                    send_dest.append(torch.full_like(rows, int(owner_np[z_hi])))
+            if send_rows:
+                rows, hd = torch.cat(send_rows), torch.cat(send_dest)
+            else:
+                rows = torch.empty(0, dtype=torch.int64, device=self.device)
+                hd = torch.empty(0, dtype=torch.int64, device=self.device)
+            (halo,) = self._exchange([self.posm.index_select(0, rows)], hd)
+            self.halo_bodies = int(halo.shape[0])
+        n_loc = self.posm.shape[0]
+        if n_loc == 0:
+            self.acc = torch.zeros((0, 4), dtype=torch.float32, device=self.device)
+            return
+        allb = self.posm if halo is None or halo.shape[0] == 0 else torch.cat([self.posm, halo]).contiguous()
+        acc_all = b.hash_forces(allb, lo + hi, self.cell, self.cutoff, self.G, self.eps)
+        self.acc_new = acc_all[:n_loc].contiguous()
+
+    def initial_forces(self):
+        self.compute_forces()
+        if self.posm.shape[0]:
+            self.acc = self.acc_new
+
+    def step(self, dt: float):
+        b = self.backend
+        if self.posm.shape[0]:
+            b.drift(self.posm, self.vel, self.acc, dt)
+        # self.acc (= a_old) migrates with the bodies inside compute_forces
+        self.compute_forces()
+        if self.posm.shape[0]:
+            b.kick(self.vel, self.acc, self.acc_new, dt)
+            self.acc = self.acc_new
+
+    def gather_global(self):
+        """(gid, posm, vel, acc) of all bodies on every rank, ordered by global id (test helper)."""
+        parts = [self.gid.double().unsqueeze(1), self.posm.double(), self.vel.double(), self.acc.double()]
+        loc = torch.cat(parts, 1).contiguous()
+        if self.world == 1:
+            full = loc
+        else:
+            counts = torch.tensor([loc.shape[0]], dtype=torch.int64, device=self.device)
+            allc = [torch.zeros_like(counts) for _ in range(self.world)]
+            dist.all_gather(allc, counts, group=self.group)
+            sizes = [int(c.item()) for c in allc]
+            cap = max(max(sizes), 1)
+            padded = torch.zeros((cap, loc.shape[1]), dtype=loc.dtype, device=self.device)
+            padded[: loc.shape[0]] = loc
+            bufs = [torch.empty_like(padded) for _ in sizes]
+            dist.all_gather(bufs, padded, group=self.group)
+            full = torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+        full = full[torch.argsort(full[:, 0])].cpu().numpy()
+        return full[:, 0].astype(np.int64), full[:, 1:5].astype(np.float32), \
+            full[:, 5:9].astype(np.float32), full[:, 9:13].astype(np.float32)

@@ -368,13 +368,12 @@ ORACLE_API void oracle_hash_grid(size_t n, const float* x, const float* y, const
   oracle_grid_dims(bmin, bmax, cell_size, dims);
 }
 
-ORACLE_API int oracle_spatial_hash_forces(size_t n, const float* x, const float* y,
-                                          const float* z, const float* m, float* ax, float* ay,
-                                          float* az, float G, float eps2, float cell_size,
-                                          float cutoff) {
-  float bmin[3], bmax[3];
-  int dims[3];
-  oracle_hash_grid(n, x, y, z, cell_size, bmin, bmax, dims);
+/* Forces on an EXPLICIT grid (origin bmin, dims): the sharded path bins every rank's bodies on
+ * the global grid.  n_t <= n: only the first n_t bodies are targets (own bodies first, then halo). */
+ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float* x, const float* y,
+                                               const float* z, const float* m, float* ax, float* ay,
+                                               float* az, float G, float eps2, float cell_size,
+                                               float cutoff, const float bmin[3], const int dims[3]) {
   long long cells = (long long)dims[0] * dims[1] * dims[2];
   if (cells > 100000000LL) return -1; /* force_spatial_hash.cu:252-254 */
   int* cell_of = (int*)malloc(n * sizeof(int));
@@ -389,7 +388,7 @@ ORACLE_API int oracle_spatial_hash_forces(size_t n, const float* x, const float*
   free(fill);
   const float cutoff2 = cutoff * cutoff; /* :100 */
 #pragma omp parallel for schedule(dynamic, 256)
-  for (long long i = 0; i < (long long)n; i++) {
+  for (long long i = 0; i < (long long)n_t; i++) {
     float xi = x[i], yi = y[i], zi = z[i];
     int cx = clampi((int)floorf((xi - bmin[0]) / cell_size), 0, dims[0] - 1);
     int cy = clampi((int)floorf((yi - bmin[1]) / cell_size), 0, dims[1] - 1);
@@ -421,6 +420,17 @@ ORACLE_API int oracle_spatial_hash_forces(size_t n, const float* x, const float*
   }
   free(cell_of); free(start); free(order);
   return 0;
+}
+
+ORACLE_API int oracle_spatial_hash_forces(size_t n, const float* x, const float* y,
+                                          const float* z, const float* m, float* ax, float* ay,
+                                          float* az, float G, float eps2, float cell_size,
+                                          float cutoff) {
+  float bmin[3], bmax[3];
+  int dims[3];
+  oracle_hash_grid(n, x, y, z, cell_size, bmin, bmax, dims);
+  return oracle_spatial_hash_forces_grid(n, n, x, y, z, m, ax, ay, az, G, eps2, cell_size, cutoff,
+                                         bmin, dims);
 }
 
 /* Direct sum restricted to pairs with unsoftened r^2 < cutoff^2: what the

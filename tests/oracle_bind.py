@@ -49,6 +49,9 @@ class Oracle:
         L.oracle_spatial_hash_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, _f, _f, _f, C.c_float,
                                                  C.c_float, C.c_float, C.c_float]
         L.oracle_spatial_hash_forces.restype = C.c_int
+        L.oracle_spatial_hash_forces_grid.argtypes = [C.c_size_t, C.c_size_t, _f, _f, _f, _f, _f, _f, _f,
+                                                      C.c_float, C.c_float, C.c_float, C.c_float, _f3, _i3]
+        L.oracle_spatial_hash_forces_grid.restype = C.c_int
         L.oracle_direct_cutoff_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, C.c_size_t, _i64, _f, _f,
                                                   _f, C.c_float, C.c_float, C.c_float]
         L.oracle_barnes_hut_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, C.c_size_t, _i64, _f, _f, _f,
@@ -129,6 +132,14 @@ class Oracle:
     def spatial_hash_forces(self, x, y, z, m, G, eps2, cell, cutoff):
         ax, ay, az = (np.empty(x.size, np.float32) for _ in range(3))
         rc = self.L.oracle_spatial_hash_forces(x.size, x, y, z, m, ax, ay, az, G, eps2, cell, cutoff)
+        if rc:
+            raise RuntimeError("grid too large")
+        return ax, ay, az
+
+    def spatial_hash_forces_grid(self, x, y, z, m, n_t, G, eps2, cell, cutoff, bmin, dims):
+        ax, ay, az = (np.empty(n_t, np.float32) for _ in range(3))
+        rc = self.L.oracle_spatial_hash_forces_grid(x.size, n_t, x, y, z, m, ax, ay, az, G, eps2, cell,
+                                                    cutoff, _f3(*bmin), _i3(*dims))
         if rc:
             raise RuntimeError("grid too large")
         return ax, ay, az

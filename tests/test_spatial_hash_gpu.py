@@ -167,3 +167,50 @@ def test_uniform_box_16_per_cell(nb, oracle, ctx, n, half):
     dc = np.stack(oracle.direct_cutoff_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
                                               1.0, float(np.float32(0.01) ** 2), 1.0), 1)
     assert rel_err(a[idx], dc).max() < TOL
+
+
+# the sharded (z-slab) path's building blocks on one GPU: global-box binning, cell_z, and
+# [own; halo] evaluation == the single-grid result for every slab of a 4-way split
+@pytest.mark.parametrize("cutoff", [1.0, 2.0])
+def test_packed_slabs_equal_whole(nb, oracle, ctx, cutoff):
+    from nbody_amd.distributed import HipBackend, ShardedHashSystem, layer_owner
+    n, cell, eps, G = 20000, 1.0, 0.05, 1.2
+    ic = nb.ic.uniform_box(n, seed=21, lo=-6.0, hi=6.0, min_mass=0.5, max_mass=1.5)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(cell, cutoff)
+    calc.setGravitationalConstant(G)
+    calc.setSofteningParameter(eps)
+    calc.computeForces(d)
+    whole = acc_of(d)
+    be = HipBackend(ctx)
+    p = torch.from_numpy(np.ascontiguousarray(
+        np.stack([ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"]], 1))).cuda()
+    bb = be.bbox(p).cpu().numpy()
+    assert np.array_equal(bb[:3], [ic[k].min() for k in ("pos_x", "pos_y", "pos_z")])
+    assert np.array_equal(bb[3:], [ic[k].max() for k in ("pos_x", "pos_y", "pos_z")])
+    sysm = ShardedHashSystem(ic, G, eps, cell, cutoff, backend=be)  # world 1: grid helpers only
+    lo, hi, dims = sysm._grid_from_bounds(bb.tolist())
+    glo, ghi = calc.getGrid().getBoundingBox()
+    assert np.allclose(lo, glo, atol=0) and np.allclose(hi, ghi, atol=0)
+    assert tuple(dims) == calc.getGrid().getGridDims()
+    cz = be.cell_z(p, lo[2], cell, dims[2]).cpu().numpy()
+    _, _, pc, _ = calc.getGrid().copyCellDataToHost()
+    assert np.array_equal(cz, pc // (dims[0] * dims[1]))
+    owner = layer_owner(dims[2], 4)
+    for r in range(4):
+        layers = np.nonzero(owner == r)[0]
+        own = np.nonzero(owner[cz] == r)[0]
+        halo = np.nonzero((cz == layers[0] - 1) | (cz == layers[-1] + 1))[0]
+        allb = torch.cat([p[torch.from_numpy(own).cuda()], p[torch.from_numpy(halo).cuda()]]).contiguous()
+        acc = be.hash_forces(allb, lo + hi, cell, cutoff, G, eps).cpu().numpy()[: own.size, :3]
+        nz = np.linalg.norm(whole[own], axis=1) > 0
+        assert rel_err(acc[nz], whole[own][nz]).max() < TOL  # summation order differs per slab
+        assert np.all(acc[~nz] == 0)
+    # world-1 system: a full step equals Integrator.integrate with the SoA calculator
+    sysm.initial_forces()
+    sysm.step(1e-3)
+    integ = nb.Integrator()
+    integ.integrate(d, calc, 1e-3)
+    gid, pos, vel, acc = sysm.gather_global()
+    assert np.allclose(pos[:, 0], d.pos_x.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert np.allclose(vel[:, 1], d.vel_y.cpu().numpy(), rtol=1e-5, atol=1e-6)
