@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane override")
     ap.add_argument("--splits", type=int, default=0, help="source splits override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the multi-GPU (RCCL) code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--kernel-iters", type=int, default=3, help="launches for the roofline timing")
     return ap.parse_args()
@@ -142,8 +144,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or a.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import nbody_amd as nb
@@ -158,11 +164,11 @@ def main():
     G, eps, dt = 1.0, a.eps, a.dt
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if not sharded:
         # the drop-in path: 13-array ParticleData behind ForceCalculator / Integrator
         d = nb.ParticleData()
         nb.ParticleDataManager.allocateDevice(d, n)
@@ -192,7 +198,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -234,7 +240,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, eps, a.cpu_seconds)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

@@ -121,7 +121,7 @@ class ShardedDirectSystem:
         b = self.backend
         S, r = self.S, self.rank
         work = None
-        if self.world > 1:
+        if dist.is_initialized():  # also with one rank: same code path as the N-GPU run
             work = dist.all_gather_into_tensor(self.posm_all, self.posm, group=self.group,
                                                async_op=True)
         # own shard against itself while the gather is in flight
