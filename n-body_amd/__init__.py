@@ -13,3 +13,5 @@ from .api import (BarnesHutCalculator, BarnesHutTree, Context, DirectForceCalcul
                   SimulationConfig, SpatialHashCalculator, SpatialHashGrid,
                   createForceCalculator, default_context,
                   direct_forces_packed, pack_posm, time_direct_packed)
+from .system import (MAX_PARTICLE_COUNT, NBODY_MAGIC, NBODY_VERSION, ParticleSystem,  # noqa: F401,E402
+                     Serializer, SimulationState)

@@ -1,0 +1,129 @@
+"""`.nbody` checkpoint and SimulationState, CPU-only.
+Format pinned three ways: the reference's documented layout (serialization.hpp:36-65: 56-byte
+header, magic 0x4E424F44, version 1, then 7 raw fp32 arrays), cross-reading with the reference's
+OWN Serializer (oracle/_ref/ref_serializer_driver, built from /root/reference by
+oracle/Makefile.ref; skipped where that binary is absent), and round trips."""
+import io
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_serializer_driver")
+
+
+def _state(nb, n=100, seed=1):
+    rng = np.random.default_rng(seed)
+    st = nb.SimulationState(particle_count=n, simulation_time=0.75, dt=0.002, G=1.5, softening=0.05,
+                            force_method=nb.ForceMethod.SPATIAL_HASH)
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass"):
+        setattr(st, k, rng.normal(0, 3, n).astype(np.float32))
+    return st
+
+
+def _fnv(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a, dtype="<f4").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_header_layout_and_round_trip(nb, tmp_path):
+    st = _state(nb)
+    buf = io.BytesIO()
+    nb.Serializer.save(buf, st)
+    raw = buf.getvalue()
+    assert len(raw) == 56 + 7 * 4 * 100
+    magic, version, count = struct.unpack_from("<IIQ", raw, 0)
+    assert (magic, version, count) == (0x4E424F44, 1, 100)
+    assert struct.unpack_from("<ffffI", raw, 16) == pytest.approx((0.75, 0.002, 1.5, 0.05, 2))
+    assert raw[36:56] == bytes(20)  # reserved[4] + struct padding
+    assert np.array_equal(np.frombuffer(raw, "<f4", 100, 56), st.pos_x)
+    assert np.array_equal(np.frombuffer(raw, "<f4", 100, 56 + 6 * 400), st.mass)
+    back = nb.Serializer.load(io.BytesIO(raw))
+    assert back == st and back.force_method == nb.ForceMethod.SPATIAL_HASH
+    p = tmp_path / "a.nbody"
+    nb.Serializer.save(str(p), st)
+    assert nb.Serializer.validateFile(str(p)) and nb.Serializer.load(str(p)) == st
+    # tests/test_serialization.cpp: equality is tolerant to 1e-6, not to more
+    other = nb.Serializer.load(str(p))
+    other.pos_x[3] += np.float32(1e-3)
+    assert other != st
+
+
+def test_error_behaviour(nb, tmp_path):
+    st = _state(nb, 10)
+    buf = io.BytesIO()
+    nb.Serializer.save(buf, st)
+    raw = bytearray(buf.getvalue())
+    with pytest.raises(RuntimeError, match="truncated"):
+        nb.Serializer.load(io.BytesIO(bytes(raw[:40])))
+    with pytest.raises(RuntimeError, match="truncated"):
+        nb.Serializer.load(io.BytesIO(bytes(raw[:-5])))
+    bad = bytearray(raw); bad[0] ^= 0xFF
+    with pytest.raises(RuntimeError, match="magic"):
+        nb.Serializer.load(io.BytesIO(bytes(bad)))
+    bad = bytearray(raw); bad[4] = 9
+    with pytest.raises(RuntimeError, match="version"):
+        nb.Serializer.load(io.BytesIO(bytes(bad)))
+    bad = bytearray(raw); struct.pack_into("<Q", bad, 8, 100_000_001)
+    with pytest.raises(nb.ValidationException):
+        nb.Serializer.load(io.BytesIO(bytes(bad)))
+    assert not nb.Serializer.validateFile(str(tmp_path / "missing.nbody"))
+    with pytest.raises(RuntimeError, match="reading"):
+        nb.Serializer.load(str(tmp_path / "missing.nbody"))
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built (needs /root/reference)")
+def test_cross_read_with_reference_serializer(nb, tmp_path):
+    # ours -> reference
+    st = _state(nb, 257, seed=5)
+    mine = tmp_path / "mine.nbody"
+    nb.Serializer.save(str(mine), st)
+    out = subprocess.run([DRIVER, "load", str(mine)], capture_output=True, text=True, check=True).stdout
+    f = dict(line.split(" ", 1) for line in out.strip().splitlines())
+    assert int(f["count"]) == 257 and int(f["method"]) == 2 and f["valid"] == "1"
+    assert float(f["time"]) == np.float32(0.75) and float(f["dt"]) == pytest.approx(float(np.float32(0.002)))
+    assert float(f["G"]) == 1.5 and float(f["softening"]) == pytest.approx(float(np.float32(0.05)))
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass"):
+        n, h = f[k].split()
+        assert int(n) == 257 and int(h) == _fnv(getattr(st, k)), k
+    # reference -> ours
+    theirs = tmp_path / "theirs.nbody"
+    subprocess.run([DRIVER, "save", str(theirs), "1000", "12345"], check=True)
+    got = nb.Serializer.load(str(theirs))
+    assert got.particle_count == 1000 and got.force_method == nb.ForceMethod.BARNES_HUT
+    assert (got.simulation_time, got.G) == (1.25, 1.5)
+    out = subprocess.run([DRIVER, "load", str(theirs)], capture_output=True, text=True, check=True).stdout
+    f = dict(line.split(" ", 1) for line in out.strip().splitlines())
+    for k in ("pos_x", "vel_z", "mass"):
+        assert int(f[k].split()[1]) == _fnv(getattr(got, k)), k
+    # re-saving the reference's file reproduces it byte for byte (except the 4 padding bytes of the
+    # header, which the reference leaves uninitialised)
+    again = tmp_path / "again.nbody"
+    nb.Serializer.save(str(again), got)
+    a, b = theirs.read_bytes(), again.read_bytes()
+    assert len(a) == len(b) and a[:52] == b[:52] and a[56:] == b[56:]
+
+
+# tests/test_serialization.cpp:222-283 CheckpointRoundTrip, counts 0, 1, 10, 100, 1000, 10000
+@pytest.mark.parametrize("count", [0, 1, 10, 100, 1000, 10000])
+def test_checkpoint_round_trip_counts(nb, count):
+    i = np.arange(count, dtype=np.float64)
+    st = nb.SimulationState(particle_count=count, simulation_time=42.5, dt=0.002, G=6.674, softening=0.05,
+                            force_method=nb.ForceMethod.DIRECT_N2)
+    for k, f in (("pos_x", 1.1), ("pos_y", 2.2), ("pos_z", 3.3), ("vel_x", 0.1), ("vel_y", 0.2), ("vel_z", 0.3)):
+        setattr(st, k, (i * f).astype(np.float32))
+    st.mass = (1.0 + i * 0.01).astype(np.float32)
+    buf = io.BytesIO()
+    nb.Serializer.save(buf, st)
+    buf.seek(0)
+    back = nb.Serializer.load(buf)
+    assert back.particle_count == count and back.force_method == nb.ForceMethod.DIRECT_N2
+    for k in ("simulation_time", "dt", "G", "softening"):
+        assert abs(getattr(back, k) - getattr(st, k)) < 1e-6
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass"):
+        assert np.array_equal(getattr(back, k), getattr(st, k))
