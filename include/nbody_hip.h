@@ -126,6 +126,15 @@ NBODY_HIP_API int nbody_hip_direct_forces_packed(nbody_hip_ctx* ctx, const nbody
                                    size_t n_sources, nbody_float4* acc_out, float G, float eps2,
                                    int accumulate);
 
+/* Two DISJOINT body sets a and b, every a x b pair evaluated ONCE (Newton's third law):
+ * acc_a (+)= forces on a from b, acc_b (+)= forces on b from a.  The sharded path uses it so that
+ * a pair of shards is computed by one rank only; the reactions travel back in a reduce-scatter.
+ * Needs eps2 >= 1e-12. */
+NBODY_HIP_API int nbody_hip_direct_forces_pair_packed(nbody_hip_ctx* ctx, const nbody_float4* a, size_t n_a,
+                                                      const nbody_float4* b, size_t n_b, nbody_float4* acc_a,
+                                                      int accumulate_a, nbody_float4* acc_b, int accumulate_b,
+                                                      float G, float eps2);
+
 /* SoA <-> packed conversion on device (x,y,z,mass -> float4 and back). */
 NBODY_HIP_API int nbody_hip_pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z,
                         const float* mass, size_t count, nbody_float4* out);
@@ -257,8 +266,9 @@ NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_f
                                  float* ms_per_launch);
 
 /* Tuning knobs for experiments.  variant: -1 automatic, 0 scalar body + LDS sources, 1 packed
- * (v_pk_*_f32) body + LDS sources, 2 scalar body + scalar-cache sources; the others 0 = automatic:
- * targets_per_lane: 1, 2 or 4; source_splits: number of source sub-ranges per target block. */
+ * (v_pk_*_f32) body + LDS sources, 2 scalar body + scalar-cache sources, 3 symmetric (action =
+ * -reaction) kernel whenever targets == sources; the others 0 = automatic:
+ * targets_per_lane: 1, 2 or 4 (6, 8: symmetric kernel only); source_splits: number of source sub-ranges per target block. */
 NBODY_HIP_API int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
                             int source_splits);
 

@@ -12,6 +12,7 @@ from .api import (BarnesHutCalculator, BarnesHutTree, Context, DirectForceCalcul
                   InitDistribution, Integrator, ParticleData, ParticleDataManager,
                   SimulationConfig, SpatialHashCalculator, SpatialHashGrid,
                   createForceCalculator, default_context,
-                  direct_forces_packed, pack_posm, time_direct_packed)
+                  direct_forces_pair_packed, direct_forces_packed, pack_posm,
+                  time_direct_packed)
 from .system import (MAX_PARTICLE_COUNT, NBODY_MAGIC, NBODY_VERSION, ParticleSystem,  # noqa: F401,E402
                      Serializer, SimulationState)

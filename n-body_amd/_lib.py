@@ -66,6 +66,8 @@ PROTOTYPES = {
     "nbody_hip_direct_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_int]),
     "nbody_hip_direct_forces_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P,
                                                  C.c_float, C.c_float, C.c_int]),
+    "nbody_hip_direct_forces_pair_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_int, _P,
+                                                      C.c_int, C.c_float, C.c_float]),
     "nbody_hip_pack_posm": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),
     "nbody_hip_unpack3": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
     "nbody_hip_update_positions": (C.c_int, [_P, _PD, C.c_float]),

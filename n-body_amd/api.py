@@ -660,6 +660,19 @@ def direct_forces_packed(ctx: Context, targets: torch.Tensor, sources: torch.Ten
     return out
 
 
+def direct_forces_pair_packed(ctx: Context, a: torch.Tensor, b: torch.Tensor, G: float, eps2: float,
+                              acc_a: torch.Tensor, acc_b: torch.Tensor, accumulate_a: bool = False,
+                              accumulate_b: bool = False):
+    """Two disjoint body sets, each a x b pair evaluated once: acc_a (+)= forces on a from b,
+    acc_b (+)= forces on b from a (the reactions)."""
+    for t in (a, b, acc_a, acc_b):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == 4
+    assert acc_a.shape == a.shape and acc_b.shape == b.shape
+    check(ctx._lib.nbody_hip_direct_forces_pair_packed(
+        ctx.handle, a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], acc_a.data_ptr(),
+        1 if accumulate_a else 0, acc_b.data_ptr(), 1 if accumulate_b else 0, G, eps2))
+
+
 def time_direct_packed(ctx: Context, targets, sources, G, eps2, iters: int, out=None) -> float:
     nt, ns = targets.shape[0], sources.shape[0]
     if out is None:

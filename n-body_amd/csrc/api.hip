@@ -261,6 +261,22 @@ extern "C" int nbody_hip_direct_forces_packed(nbody_hip_ctx* ctx, const nbody_fl
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
 }
 
+extern "C" int nbody_hip_direct_forces_pair_packed(nbody_hip_ctx* ctx, const nbody_float4* a, size_t n_a,
+                                                   const nbody_float4* b, size_t n_b, nbody_float4* acc_a,
+                                                   int accumulate_a, nbody_float4* acc_b, int accumulate_b,
+                                                   float G, float eps2) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (n_a == 0 || n_b == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "both body sets must be non-empty");
+  if (!a || !b || !acc_a || !acc_b) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (n_a > 0x3fffffffu || n_b > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");
+  if (!(eps2 >= 1e-12f))
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "pair evaluation needs eps2 >= 1e-12 (use the one-sided entry point)");
+  NBH_HIP(hipSetDevice(ctx->device));
+  return direct_symmetric_pair(ctx, reinterpret_cast<const float4*>(a), n_a, reinterpret_cast<const float4*>(b),
+                               n_b, G, eps2, reinterpret_cast<float4*>(acc_a), accumulate_a,
+                               reinterpret_cast<float4*>(acc_b), accumulate_b);
+}
+
 extern "C" int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_float4* targets,
                                             size_t n_targets, const nbody_float4* sources,
                                             size_t n_sources, nbody_float4* acc_out, float G,
@@ -286,9 +302,10 @@ extern "C" int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_floa
 extern "C" int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
                                        int source_splits) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
-  if (variant < -1 || variant > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "variant must be -1 (auto), 0, 1 or 2");
-  if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4)
-    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "targets_per_lane must be 0 (auto), 1, 2 or 4");
+  if (variant < -1 || variant > 3) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "variant must be -1 (auto), 0, 1, 2 or 3");
+  if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4 &&
+      targets_per_lane != 6 && targets_per_lane != 8)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "targets_per_lane must be 0 (auto), 1, 2, 4 (6, 8: symmetric kernel only)");
   if (source_splits < 0 || source_splits > 4096)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "source_splits must be in [0, 4096]");
   ctx->tune_variant = variant;

@@ -68,6 +68,15 @@ int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
                   // optional fused velocity update (soa output only): v += (a_old + a) * half_dt
                   float* vx, float* vy, float* vz, const float* aox, const float* aoy,
                   const float* aoz, float half_dt);
+// direct_sym.hip: all-pairs with action = -reaction (targets == sources)
+int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
+                     float4* acc4, int accumulate, float* ax, float* ay, float* az, float* vx,
+                     float* vy, float* vz, const float* aox, const float* aoy, const float* aoz,
+                     float half_dt);
+int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const float4* pj, size_t nj,
+                          float G, float eps2, float4* acc_i, int accumulate_i, float4* acc_j,
+                          int accumulate_j);
+bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n);
 int pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m,
               size_t n, float4* out);
 

@@ -286,6 +286,11 @@ int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30 (int indexing, ref: force_direct.cu:89)");
   if (!(eps2 >= 0.0f)) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "eps2 must be >= 0");
 
+  // symmetric (Newton's third law) kernel: the all-pairs case on one device
+  if (targets == sources && n_targets == n_sources && eps2 >= 1e-12f && symmetric_pays(ctx, n_targets))
+    return direct_symmetric(ctx, targets, n_targets, G, eps2, acc4, accumulate, ax, ay, az, vx, vy,
+                            vz, aox, aoy, aoz, half_dt);
+
   const Shape s = choose_shape(ctx, n_targets, n_sources);
   int rc = ctx->partial.reserve((size_t)s.splits * s.n_tgt_pad * sizeof(float4));
   if (rc) return rc;

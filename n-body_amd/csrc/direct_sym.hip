@@ -1,0 +1,289 @@
+// direct_sym.hip -- Direct N^2 exploiting Newton's third law (action = -reaction), gfx950.
+//
+// Same sum as direct.hip (and as computeForcesDirectKernel, src/cuda/force_direct.cu:10-85):
+//     a_i = G sum_{j != i} m_j (r_j - r_i) (|r_j - r_i|^2 + eps^2)^(-3/2),
+// but every UNORDERED pair {i, j} is evaluated once and used twice: the shared factor
+// g = (d^2 + eps^2)^(-3/2) costs 3 sub + 3 fma + 1 rsq + 2 mul, then a_i += (g m_j) d and
+// a_j -= (g m_i) d are 2 mul + 6 fma: 20 issue slots per unordered pair = 10 per ordered pair,
+// against 16 for the one-sided kernel (the rsq alone is 4 slots, measured).
+//
+// Mapping.  Bodies are cut into superblocks of S = 256 R bodies.  Workgroup (A, split) holds
+// superblock A in REGISTERS (each lane R bodies, the "I side") and walks the partner superblocks
+// B = A + d (mod NB), d in its share of 0 .. NB/2 (a half ring: every unordered superblock pair
+// exactly once; d = 0 is the diagonal, handled without reaction).  A partner is visited in chunks
+// of 64 bodies (the "J side"): every wave loads the chunk with lane l holding J body l, together
+// with a reaction accumulator that TRAVELS WITH THE BODY.  In each of 64 steps a lane pairs its R
+// bodies with the J body it currently holds, adds the reaction into the travelling accumulator,
+// and the seven J registers {x, y, z, m, hx, hy, hz} are rotated one lane along the wave
+// (v_mov_b32_dpp wave_ror:1).  After 64 steps everything is back in its home lane.  The four
+// waves of the block then combine their reactions through LDS (plain stores + barrier) and one
+// wave adds the 64 x 3 sums to the global fp64 accumulator with hardware f64 atomics (lossless
+// across XCDs, measured ~180 G adds/s).  The I-side sums stay in registers for the whole kernel
+// (fp32 per 4 chunks, folded into fp64) and are added once at the end.
+//
+// Not bitwise reproducible (atomic order), unlike direct.hip; agreement with the oracle is the
+// same 1e-5.  Used for the single-GPU all-pairs case (targets == sources); the one-sided kernel
+// remains the path for rectangular target/source sets (sharded runs) and for eps^2 < 1e-12.
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace nbh {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// one-lane rotation of a wave64 register: lane l receives the value of lane (l + 1) & 63
+__device__ __forceinline__ float wave_rot1(float v) {
+  // mov_dpp (no "old" operand): every lane is written, so nothing has to be initialised first
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x134 /* wave_rol:1 */, 0xF, 0xF, false));
+}
+
+// R even.  grid = (NB_I, splits), block = 256.
+// RECT = false: one body set; partner offsets d in 0 .. NB/2 (half ring), d = 0 without reaction.
+// RECT = true : two DISJOINT body sets I (n bodies, posm) and J (nj bodies, posj): every I x J pair
+//               once; offsets d = 0 .. NBJ-1 address the J superblocks directly; the reactions go to
+//               accj64 (the sharded path sends them back to the owner of the J bodies).
+template <int R, bool RECT>
+__global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __restrict__ posm, int n,
+                                                            const float4* __restrict__ posj, int nj,
+                                                            int NB, int NBJ, int offsets_per_split,
+                                                            double* __restrict__ acc64,
+                                                            double* __restrict__ accj64,
+                                                            float eps2) {
+  constexpr int S = kBlock * R;
+  __shared__ float slab[2][4][3][64];  // per-wave reaction sums of a chunk, double buffered
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int A = blockIdx.x;
+  const int D = RECT ? NBJ - 1 : NB / 2;     // largest partner offset
+  const int d0 = blockIdx.y * offsets_per_split;
+  const int d1 = min(D + 1, d0 + offsets_per_split);
+  if (d0 >= d1) return;
+
+  // I side: R bodies per lane, packed in pairs
+  f2 xi[R / 2], yi[R / 2], zi[R / 2], mi[R / 2];
+#pragma unroll
+  for (int r = 0; r < R / 2; r++) {
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+    const int i0 = A * S + (2 * r) * kBlock + tid, i1 = i0 + kBlock;
+    if (i0 < n) p0 = posm[i0];
+    if (i1 < n) p1 = posm[i1];
+    xi[r] = f2{p0.x, p1.x}; yi[r] = f2{p0.y, p1.y}; zi[r] = f2{p0.z, p1.z}; mi[r] = f2{p0.w, p1.w};
+  }
+  double sx[R], sy[R], sz[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) sx[r] = sy[r] = sz[r] = 0.0;
+  f2 ax[R / 2], ay[R / 2], az[R / 2];
+#pragma unroll
+  for (int r = 0; r < R / 2; r++) ax[r] = ay[r] = az[r] = f2{0.f, 0.f};
+  const f2 e2 = {eps2, eps2};
+
+  // flat list of chunks: (offset d, chunk c of the partner); S/64 chunks per partner
+  constexpr int CPB = S / 64;
+  // partner d is skipped when the half ring would visit the pair twice (NB even, d = NB/2, upper half)
+  auto partner_valid = [&](int d) { return RECT || !((NB % 2 == 0) && d == D && d > 0 && A >= D); };
+  const int nchunks = (d1 - d0) * CPB;
+
+  auto load_chunk = [&](int q) -> float4 {  // q-th chunk of this block's list, body `lane`
+    const int d = d0 + q / CPB, c = q % CPB;
+    const int B = RECT ? d : (A + d) % NB;
+    const int j = B * S + c * 64 + lane;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RECT) { if (j < nj) p = posj[j]; }
+    else if (j < n && partner_valid(d)) p = posm[j];
+    return p;  // invalid partner / padding: zero mass at the origin -> contributes nothing
+  };
+  auto flush_chunk = [&](int q) {  // one wave: combine the four waves' sums of chunk q, add to global
+    const int pd = d0 + q / CPB, pc = q % CPB;
+    if ((RECT || pd > 0) && partner_valid(pd)) {
+      const int j = (RECT ? pd : (A + pd) % NB) * S + pc * 64 + lane;
+      const int sb = q & 1;
+      double* dst = RECT ? accj64 : acc64;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float v = (slab[sb][0][c][lane] + slab[sb][1][c][lane]) + (slab[sb][2][c][lane] + slab[sb][3][c][lane]);
+        unsafeAtomicAdd(&dst[(size_t)j * 4 + c], (double)v);
+      }
+    }
+  };
+
+  float4 jnext = load_chunk(0);
+  for (int q = 0; q < nchunks; q++) {
+    const float4 jcur = jnext;
+    if (q + 1 < nchunks) jnext = load_chunk(q + 1);  // next chunk in flight under the math
+    const int d = d0 + q / CPB;
+    const bool react = RECT || d > 0;  // the diagonal superblock pair sees every ordered pair already
+    if (q > 0) {
+      __syncthreads();  // every wave has stored its sums of chunk q-1
+      if (w == (q & 3)) flush_chunk(q - 1);
+    }
+    float jx = jcur.x, jy = jcur.y, jz = jcur.z, jm = jcur.w;
+    float hjx = 0.f, hjy = 0.f, hjz = 0.f;
+    auto steps = [&](auto react_tag) {
+      constexpr bool REACT = decltype(react_tag)::value;
+#pragma unroll 2
+      for (int k = 0; k < 64; k++) {
+        const f2 sxj = {jx, jx}, syj = {jy, jy}, szj = {jz, jz}, smj = {jm, jm};
+        // the travelling reaction sum rides in the low half of the packed accumulator
+        f2 hx = {hjx, 0.f}, hy = {hjy, 0.f}, hz = {hjz, 0.f};
+#pragma unroll
+        for (int r = 0; r < R / 2; r++) {
+          const f2 dx = sxj - xi[r], dy = syj - yi[r], dz = szj - zi[r];
+          const f2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, e2)));
+          f2 inv;
+          inv.x = __builtin_amdgcn_rsqf(r2.x);
+          inv.y = __builtin_amdgcn_rsqf(r2.y);
+          const f2 g = (inv * inv) * inv;
+          const f2 fj = g * smj;    // on the I bodies, from J
+          ax[r] = __builtin_elementwise_fma(fj, dx, ax[r]);
+          ay[r] = __builtin_elementwise_fma(fj, dy, ay[r]);
+          az[r] = __builtin_elementwise_fma(fj, dz, az[r]);
+          if (REACT) {
+            const f2 fi = g * mi[r];  // on the J body, from the I bodies
+            hx = __builtin_elementwise_fma(-fi, dx, hx);  // a_j -= g m_i d  (neg is an operand modifier)
+            hy = __builtin_elementwise_fma(-fi, dy, hy);
+            hz = __builtin_elementwise_fma(-fi, dz, hz);
+          }
+        }
+        if (REACT) {
+          hjx = wave_rot1(hx.x + hx.y); hjy = wave_rot1(hy.x + hy.y); hjz = wave_rot1(hz.x + hz.y);
+        }
+        jx = wave_rot1(jx); jy = wave_rot1(jy); jz = wave_rot1(jz); jm = wave_rot1(jm);
+      }
+    };
+    if (react) steps(std::true_type{}); else steps(std::false_type{});
+    // after 64 one-lane rotations every J body (and its reaction sum) is back in its home lane
+    slab[q & 1][w][0][lane] = hjx; slab[q & 1][w][1][lane] = hjy; slab[q & 1][w][2][lane] = hjz;
+    if ((q & 3) == 3 || q == nchunks - 1) {  // fold the fp32 sums of <= 256 sources into fp64
+#pragma unroll
+      for (int r = 0; r < R / 2; r++) {
+        sx[2 * r] += (double)ax[r].x; sx[2 * r + 1] += (double)ax[r].y;
+        sy[2 * r] += (double)ay[r].x; sy[2 * r + 1] += (double)ay[r].y;
+        sz[2 * r] += (double)az[r].x; sz[2 * r + 1] += (double)az[r].y;
+        ax[r] = ay[r] = az[r] = f2{0.f, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+  if (w == (nchunks & 3)) flush_chunk(nchunks - 1);
+  // I side
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int i = A * S + r * kBlock + tid;  // < NB * S: the accumulator is padded to that
+    unsafeAtomicAdd(&acc64[(size_t)i * 4 + 0], sx[r]);
+    unsafeAtomicAdd(&acc64[(size_t)i * 4 + 1], sy[r]);
+    unsafeAtomicAdd(&acc64[(size_t)i * 4 + 2], sz[r]);
+  }
+}
+
+// acc = G * acc64 ; SoA or float4 output ; optional fused Velocity-Verlet kick
+__global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
+    const double* __restrict__ acc64, int n, float G, float4* __restrict__ acc4, int accumulate,
+    float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, float* __restrict__ vx,
+    float* __restrict__ vy, float* __restrict__ vz, const float* __restrict__ aox,
+    const float* __restrict__ aoy, const float* __restrict__ aoz, float half_dt) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double4 a = reinterpret_cast<const double4*>(acc64)[i];
+  const float fx = (float)((double)G * a.x), fy = (float)((double)G * a.y), fz = (float)((double)G * a.z);
+  if (acc4) {
+    float4 o = make_float4(fx, fy, fz, 0.f);
+    if (accumulate) { const float4 c = acc4[i]; o.x += c.x; o.y += c.y; o.z += c.z; }
+    acc4[i] = o;
+  } else {
+    ax[i] = fx; ay[i] = fy; az[i] = fz;
+    if (vx) {
+      vx[i] += (aox[i] + fx) * half_dt;
+      vy[i] += (aoy[i] + fy) * half_dt;
+      vz[i] += (aoz[i] + fz) * half_dt;
+    }
+  }
+}
+
+template <int R, bool RECT>
+static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, const float4* pj, int nj,
+                       int NB, int NBJ, int per, double* acci, double* accj, float eps2) {
+  hipLaunchKernelGGL((direct_sym_kernel<R, RECT>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj, NB,
+                     NBJ, per, acci, accj, eps2);
+}
+
+// symmetric kernel worth it from here (measured, tools/test_sym3.py): below, the one-sided kernel
+bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n) {
+  if (ctx->tune_variant == 3) return true;
+  return ctx->tune_variant < 0 && n >= 32768;
+}
+
+static int sym_R(const nbody_hip_ctx* ctx, size_t n) {
+  if (ctx->tune_tpl == 2 || ctx->tune_tpl == 4 || ctx->tune_tpl == 6 || ctx->tune_tpl == 8) return ctx->tune_tpl;
+  return n >= 262144 ? 8 : 4;  // measured: R = 8 wins from N = 2.6e5, R = 4 from 3.3e4
+}
+
+int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
+                     float4* acc4, int accumulate, float* ax, float* ay, float* az, float* vx,
+                     float* vy, float* vz, const float* aox, const float* aoy, const float* aoz,
+                     float half_dt) {
+  const int R = sym_R(ctx, n);
+  const int S = kBlock * R;
+  const int NB = (int)((n + S - 1) / S);
+  const int D = NB / 2;
+  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * 16 + NB - 1) / NB;
+  if (splits > D + 1) splits = D + 1;
+  if (splits < 1) splits = 1;
+  const int per = (D + 1 + splits - 1) / splits;
+  splits = (D + 1 + per - 1) / per;
+  const size_t acc_bytes = (size_t)NB * S * 4 * sizeof(double);
+  if (int rc = ctx->partial.reserve(acc_bytes)) return rc;
+  double* acc64 = static_cast<double*>(ctx->partial.ptr);
+  NBH_HIP(hipMemsetAsync(acc64, 0, acc_bytes, ctx->stream));
+  const dim3 grid(NB, splits);
+  const int ni = (int)n;
+  switch (R) {
+    case 2: launch_sym<2, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, eps2); break;
+    case 6: launch_sym<6, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, eps2); break;
+    case 8: launch_sym<8, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, eps2); break;
+    default: launch_sym<4, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, eps2); break;
+  }
+  NBH_LAUNCH_CHECK();
+  const int fblocks = (int)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, acc64,
+                     ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+// Two disjoint sets: acc_i (+)= forces on I from J ; acc_j = forces on J from I (the reactions).
+int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const float4* pj, size_t nj,
+                          float G, float eps2, float4* acc_i, int accumulate_i, float4* acc_j,
+                          int accumulate_j) {
+  const int R = sym_R(ctx, ni < nj ? ni : nj);
+  const int S = kBlock * R;
+  const int NBI = (int)((ni + S - 1) / S), NBJ = (int)((nj + S - 1) / S);
+  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * 16 + NBI - 1) / NBI;
+  if (splits > NBJ) splits = NBJ;
+  if (splits < 1) splits = 1;
+  const int per = (NBJ + splits - 1) / splits;
+  splits = (NBJ + per - 1) / per;
+  const size_t bi = (size_t)NBI * S * 4 * sizeof(double), bj = (size_t)NBJ * S * 4 * sizeof(double);
+  if (int rc = ctx->partial.reserve(bi + bj)) return rc;
+  double* acci = static_cast<double*>(ctx->partial.ptr);
+  double* accj = acci + (size_t)NBI * S * 4;
+  NBH_HIP(hipMemsetAsync(acci, 0, bi + bj, ctx->stream));
+  const dim3 grid(NBI, splits);
+  switch (R) {
+    case 2: launch_sym<2, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, eps2); break;
+    case 6: launch_sym<6, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, eps2); break;
+    case 8: launch_sym<8, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, eps2); break;
+    default: launch_sym<4, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, eps2); break;
+  }
+  NBH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((ni + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     ctx->stream, acci, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((nj + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     ctx->stream, accj, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+}  // namespace nbh
