@@ -8,9 +8,16 @@ exert no force).  One Velocity-Verlet step (ref: Integrator::integrate, integrat
     drift own bodies                                   (compute stream)
     all-gather {x,y,z,m} float4 of every shard         (RCCL stream; 16 B/body, 2 MiB per rank
                                                         at N = 2^20, once per step)
-    forces on own targets from OWN sources             (compute stream, overlaps the gather)
+    own shard against itself                           (compute stream, overlaps the gather)
     wait for the gather
-    forces from the shards left and right of the own range, accumulated
+    mode "pair" (default): every PAIR of shards is evaluated by ONE rank, action and reaction
+        together (Newton's third law, nbody_hip_direct_forces_pair_packed): rank r takes the
+        shards r+1 .. r+(W-1)/2 of the ring, plus half of the antipodal rectangle when W is even;
+        its contributions to everybody's accelerations go into one [N,4] buffer and a single
+        reduce-scatter (sum) hands every rank the total for its own bodies.  Per rank that is
+        N^2/(2W) pair evaluations instead of N^2/W.
+    mode "gather": forces from the shards left and right of the own range with the one-sided
+        kernel, accumulated (needed when eps^2 < 1e-12; no reduce-scatter)
     kick own bodies; swap acceleration buffers
 
 The force math is the C-ABI call nbody_hip_direct_forces_packed; `backend` only exists so that
@@ -26,7 +33,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import check
-from .api import Context, direct_forces_packed
+from .api import Context, direct_forces_pair_packed, direct_forces_packed
 
 
 class HipBackend:
@@ -46,6 +53,9 @@ class HipBackend:
 
     def forces(self, targets, sources, G, eps2, out, accumulate):
         direct_forces_packed(self.ctx, targets, sources, G, eps2, out=out, accumulate=accumulate)
+
+    def forces_pair(self, a, b, G, eps2, acc_a, acc_b, accumulate_a, accumulate_b):
+        direct_forces_pair_packed(self.ctx, a, b, G, eps2, acc_a, acc_b, accumulate_a, accumulate_b)
 
     # -- spatial hash (z-slab path) ------------------------------------------------------------
     def bbox(self, posm):
@@ -87,10 +97,31 @@ def shard_bounds(n: int, world: int, rank: int):
     return s, lo, hi
 
 
+def pair_schedule(world: int, rank: int, S: int):
+    """Shard pairs evaluated by `rank` in pair mode: list of (i0, i1, shard, j0, j1) meaning
+    own bodies [i0, i1) x bodies [j0, j1) of `shard`, each body pair of two DIFFERENT shards
+    appearing in exactly one rank's list.  Rank r takes the ring neighbours r+1 .. r+(W-1)/2; for
+    even W the antipodal rectangle is cut in half: the lower rank takes its first half x the
+    whole partner, the upper rank its whole shard x the partner's second half."""
+    out = []
+    for d in range(1, (world - 1) // 2 + 1):
+        out.append((0, S, (rank + d) % world, 0, S))
+    if world % 2 == 0 and world > 1:
+        sh = (rank + world // 2) % world
+        h = S // 2
+        if rank < world // 2:
+            if h > 0:
+                out.append((0, h, sh, 0, S))
+        else:
+            out.append((0, S, sh, h, S))
+    return out
+
+
 class ShardedDirectSystem:
     """State of one rank: its shard as packed float4 arrays + the gathered source buffer."""
 
-    def __init__(self, ic: dict, G: float, eps: float, backend=None, group=None, device=None):
+    def __init__(self, ic: dict, G: float, eps: float, backend=None, group=None, device=None,
+                 mode: str | None = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -98,6 +129,11 @@ class ShardedDirectSystem:
         self.device = torch.device(device) if device is not None else backend.device
         self.G = float(G)
         self.eps2 = float(np.float32(eps) * np.float32(eps))
+        if mode is None:
+            mode = "pair" if (self.eps2 >= 1e-12 and hasattr(backend, "forces_pair")) else "gather"
+        assert mode in ("pair", "gather")
+        self.mode = mode
+        self.contrib = None
         n = int(ic["pos_x"].size)
         self.n = n
         self.S, self.lo, self.hi = shard_bounds(n, self.world, self.rank)
@@ -124,14 +160,33 @@ class ShardedDirectSystem:
         if dist.is_initialized():  # also with one rank: same code path as the N-GPU run
             work = dist.all_gather_into_tensor(self.posm_all, self.posm, group=self.group,
                                                async_op=True)
-        # own shard against itself while the gather is in flight
-        b.forces(self.posm, self.posm, self.G, self.eps2, out, False)
-        if work is not None:
-            work.wait()  # orders the compute stream after the collective
-            if r > 0:
-                b.forces(self.posm, self.posm_all[:r * S], self.G, self.eps2, out, True)
-            if r < self.world - 1:
-                b.forces(self.posm, self.posm_all[(r + 1) * S:], self.G, self.eps2, out, True)
+        W = self.world
+        if self.mode == "gather" or W == 1:
+            # own shard against itself while the gather is in flight
+            b.forces(self.posm, self.posm, self.G, self.eps2, out, False)
+            if work is not None:
+                work.wait()  # orders the compute stream after the collective
+                if r > 0:
+                    b.forces(self.posm, self.posm_all[:r * S], self.G, self.eps2, out, True)
+                if r < W - 1:
+                    b.forces(self.posm, self.posm_all[(r + 1) * S:], self.G, self.eps2, out, True)
+            return
+        # -- pair mode: each pair of shards once, reactions returned by a reduce-scatter ---------
+        if self.contrib is None:
+            self.contrib = torch.empty((S * W, 4), dtype=torch.float32, device=self.device)
+        c = self.contrib
+        c.zero_()
+        mine = c[r * S:(r + 1) * S]
+        b.forces(self.posm, self.posm, self.G, self.eps2, mine, False)  # overlaps the gather
+        work.wait()
+        for i0, i1, sh, j0, j1 in pair_schedule(W, r, S):
+            b.forces_pair(self.posm[i0:i1], self.posm_all[sh * S + j0:sh * S + j1], self.G, self.eps2,
+                          mine[i0:i1], c[sh * S + j0:sh * S + j1], True, False)
+        if dist.get_backend(self.group) == "gloo":   # gloo has no reduce_scatter: all-reduce + slice
+            dist.all_reduce(c, group=self.group)
+            out.copy_(mine)
+        else:
+            dist.reduce_scatter_tensor(out, c, op=dist.ReduceOp.SUM, group=self.group)
 
     def initial_forces(self):
         """ref: ParticleSystem::initialize evaluates a(0) once (particle_system.cpp:88-91)."""

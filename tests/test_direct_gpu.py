@@ -287,3 +287,35 @@ def test_pair_kernel(nb, oracle, ctx):
         assert rel_err(acc_b.cpu().numpy()[:, :3], 2 * rb.cpu().numpy()[:, :3]).max() < TOL
     with pytest.raises(nb.ValidationException):
         nb.direct_forces_pair_packed(ctx, a, b, 1.0, 0.0, acc_a, acc_b)
+
+
+# the sharded "pair" mode's arithmetic with the HIP kernels, W ranks emulated one after the other
+# on one GPU: sum over ranks of the contribution buffers == the all-pairs result
+@pytest.mark.parametrize("W", [2, 3, 4, 8])
+def test_pair_mode_contributions_sum_to_whole(nb, ctx, W):
+    from nbody_amd.distributed import HipBackend, pair_schedule, shard_bounds
+    n = 48000 + W  # ragged: the last shard is padded
+    ic = nb.ic.plummer(n, seed=W)
+    eps2, G = 1e-6, 1.0
+    p = packed(ic)
+    try:
+        ctx.tuning(1, 4, 0)
+        whole = nb.direct_forces_packed(ctx, p, p, G, eps2).cpu().numpy()[:, :3]
+    finally:
+        ctx.tuning()
+    be = HipBackend(ctx)
+    S = shard_bounds(n, W, 0)[0]
+    allp = torch.zeros((W * S, 4), dtype=torch.float32, device="cuda")
+    allp[:n] = p
+    total = torch.zeros((W * S, 4), dtype=torch.float32, device="cuda")
+    for r in range(W):
+        c = torch.zeros_like(total)
+        own = allp[r * S:(r + 1) * S].contiguous()
+        mine = c[r * S:(r + 1) * S]
+        be.forces(own, own, G, eps2, mine, False)
+        for i0, i1, sh, j0, j1 in pair_schedule(W, r, S):
+            be.forces_pair(own[i0:i1], allp[sh * S + j0:sh * S + j1], G, eps2, mine[i0:i1],
+                           c[sh * S + j0:sh * S + j1], True, False)
+        total += c
+    got = total[:n].cpu().numpy()[:, :3]
+    assert rel_err(got, whole).max() < TOL

@@ -49,6 +49,10 @@ class OracleBackend:
             o[:, 3] = 0
 
 
+    def forces_pair(self, a, b, G, eps2, acc_a, acc_b, accumulate_a, accumulate_b):
+        self.forces(a, b, G, eps2, acc_a, accumulate_a)
+        self.forces(b, a, G, eps2, acc_b, accumulate_b)
+
     # -- spatial hash (z-slab path) -------------------------------------------------------------
     def bbox(self, posm):
         p = posm.numpy()
@@ -78,7 +82,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, steps, out_dir):
+def _worker(rank, world, port, n, steps, out_dir, mode=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -89,7 +93,7 @@ def _worker(rank, world, port, n, steps, out_dir):
         import nbody_amd
         from nbody_amd.distributed import ShardedDirectSystem, shard_bounds
         ic = nbody_amd.ic.plummer(n, seed=5)
-        sysm = ShardedDirectSystem(ic, 1.0, 0.01, backend=OracleBackend(), device="cpu")
+        sysm = ShardedDirectSystem(ic, 1.0, 0.01, backend=OracleBackend(), device="cpu", mode=mode)
         S, lo, hi = shard_bounds(n, world, rank)
         assert (sysm.S, sysm.lo, sysm.hi) == (S, lo, hi)
         sysm.initial_forces()
@@ -105,11 +109,12 @@ def _worker(rank, world, port, n, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 600), (3, 601)])
-def test_sharded_steps_match_single_process(tmp_path, world, n, oracle, nb):
+@pytest.mark.parametrize("world,n,mode", [(2, 600, "pair"), (3, 601, "pair"), (4, 602, "pair"),
+                                          (2, 600, "gather"), (3, 601, "gather")])
+def test_sharded_steps_match_single_process(tmp_path, world, n, mode, oracle, nb):
     from oracle_bind import host_state
     steps = 3
-    mp.spawn(_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, steps, str(tmp_path), mode), nprocs=world, join=True)
     got = np.load(tmp_path / f"w{world}.npz")
     ic = nb.ic.plummer(n, seed=5)
     s = host_state(ic)
@@ -214,3 +219,22 @@ def test_layer_owner(nb):
     assert np.bincount(o, minlength=8).min() >= 8
     o = layer_owner(3, 8)   # fewer layers than ranks: some ranks own nothing
     assert len(set(o.tolist())) == 3
+
+
+def test_pair_schedule_covers_every_pair_once(nb):
+    from nbody_amd.distributed import pair_schedule
+    for W in (1, 2, 3, 4, 5, 8):
+        for S in (1, 4, 7):
+            seen = np.zeros((W * S, W * S), dtype=np.int32)
+            for r in range(W):
+                for i0, i1, sh, j0, j1 in pair_schedule(W, r, S):
+                    assert sh != r and 0 <= i0 < i1 <= S and 0 <= j0 < j1 <= S
+                    seen[r * S + i0:r * S + i1, sh * S + j0:sh * S + j1] += 1
+            both = seen + seen.T
+            for a in range(W):
+                for b in range(W):
+                    blk = both[a * S:(a + 1) * S, b * S:(b + 1) * S]
+                    assert np.all(blk == (0 if a == b else 1)), (W, S, a, b)
+        # balance at even W: every rank evaluates the same number of body pairs
+        work = [sum((i1 - i0) * (j1 - j0) for i0, i1, _, j0, j1 in pair_schedule(W, r, 8)) for r in range(W)]
+        assert max(work) - min(work) <= 0, (W, work)
