@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
                                                             int NB, int NBJ, int offsets_per_split,
                                                             double* __restrict__ acc64,
                                                             double* __restrict__ accj64,
+                                                            size_t plane_i, size_t plane_j,
                                                             float eps2) {
   constexpr int S = kBlock * R;
   __shared__ float slab[2][4][3][64];  // per-wave reaction sums of a chunk, double buffered
@@ -99,10 +100,11 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
       const int j = (RECT ? pd : (A + pd) % NB) * S + pc * 64 + lane;
       const int sb = q & 1;
       double* dst = RECT ? accj64 : acc64;
+      const size_t plane = RECT ? plane_j : plane_i;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
+      for (int c = 0; c < 3; c++) {  // component planes: 64 lanes x 8 B contiguous per atomic instruction
         const float v = (slab[sb][0][c][lane] + slab[sb][1][c][lane]) + (slab[sb][2][c][lane] + slab[sb][3][c][lane]);
-        unsafeAtomicAdd(&dst[(size_t)j * 4 + c], (double)v);
+        unsafeAtomicAdd(&dst[c * plane + (size_t)j], (double)v);
       }
     }
   };
@@ -170,22 +172,22 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int i = A * S + r * kBlock + tid;  // < NB * S: the accumulator is padded to that
-    unsafeAtomicAdd(&acc64[(size_t)i * 4 + 0], sx[r]);
-    unsafeAtomicAdd(&acc64[(size_t)i * 4 + 1], sy[r]);
-    unsafeAtomicAdd(&acc64[(size_t)i * 4 + 2], sz[r]);
+    unsafeAtomicAdd(&acc64[(size_t)i], sx[r]);
+    unsafeAtomicAdd(&acc64[plane_i + (size_t)i], sy[r]);
+    unsafeAtomicAdd(&acc64[2 * plane_i + (size_t)i], sz[r]);
   }
 }
 
 // acc = G * acc64 ; SoA or float4 output ; optional fused Velocity-Verlet kick
 __global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
-    const double* __restrict__ acc64, int n, float G, float4* __restrict__ acc4, int accumulate,
+    const double* __restrict__ acc64, size_t plane, int n, float G, float4* __restrict__ acc4, int accumulate,
     float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, float* __restrict__ vx,
     float* __restrict__ vy, float* __restrict__ vz, const float* __restrict__ aox,
     const float* __restrict__ aoy, const float* __restrict__ aoz, float half_dt) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const double4 a = reinterpret_cast<const double4*>(acc64)[i];
-  const float fx = (float)((double)G * a.x), fy = (float)((double)G * a.y), fz = (float)((double)G * a.z);
+  const float fx = (float)((double)G * acc64[i]), fy = (float)((double)G * acc64[plane + i]),
+              fz = (float)((double)G * acc64[2 * plane + i]);
   if (acc4) {
     float4 o = make_float4(fx, fy, fz, 0.f);
     if (accumulate) { const float4 c = acc4[i]; o.x += c.x; o.y += c.y; o.z += c.z; }
@@ -203,8 +205,9 @@ __global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
 template <int R, bool RECT>
 static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, const float4* pj, int nj,
                        int NB, int NBJ, int per, double* acci, double* accj, float eps2) {
+  const size_t S = (size_t)kBlock * R;
   hipLaunchKernelGGL((direct_sym_kernel<R, RECT>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj, NB,
-                     NBJ, per, acci, accj, eps2);
+                     NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, eps2);
 }
 
 // symmetric kernel worth it from here (measured, tools/test_sym3.py): below, the one-sided kernel
@@ -231,7 +234,8 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
   if (splits < 1) splits = 1;
   const int per = (D + 1 + splits - 1) / splits;
   splits = (D + 1 + per - 1) / per;
-  const size_t acc_bytes = (size_t)NB * S * 4 * sizeof(double);
+  const size_t plane = (size_t)NB * S;
+  const size_t acc_bytes = plane * 3 * sizeof(double);  // three component planes
   if (int rc = ctx->partial.reserve(acc_bytes)) return rc;
   double* acc64 = static_cast<double*>(ctx->partial.ptr);
   NBH_HIP(hipMemsetAsync(acc64, 0, acc_bytes, ctx->stream));
@@ -246,7 +250,7 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
   NBH_LAUNCH_CHECK();
   const int fblocks = (int)((n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, acc64,
-                     ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
+                     plane, ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
@@ -263,10 +267,11 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
   if (splits < 1) splits = 1;
   const int per = (NBJ + splits - 1) / splits;
   splits = (NBJ + per - 1) / per;
-  const size_t bi = (size_t)NBI * S * 4 * sizeof(double), bj = (size_t)NBJ * S * 4 * sizeof(double);
+  const size_t plane_i = (size_t)NBI * S, plane_j = (size_t)NBJ * S;
+  const size_t bi = plane_i * 3 * sizeof(double), bj = plane_j * 3 * sizeof(double);
   if (int rc = ctx->partial.reserve(bi + bj)) return rc;
   double* acci = static_cast<double*>(ctx->partial.ptr);
-  double* accj = acci + (size_t)NBI * S * 4;
+  double* accj = acci + plane_i * 3;
   NBH_HIP(hipMemsetAsync(acci, 0, bi + bj, ctx->stream));
   const dim3 grid(NBI, splits);
   switch (R) {
@@ -277,10 +282,10 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
   }
   NBH_LAUNCH_CHECK();
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((ni + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, acci, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
+                     ctx->stream, acci, plane_i, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((nj + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, accj, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
+                     ctx->stream, accj, plane_j, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
