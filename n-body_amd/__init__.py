@@ -16,3 +16,4 @@ from .api import (BarnesHutCalculator, BarnesHutTree, Context, DirectForceCalcul
                   time_direct_packed)
 from .system import (MAX_PARTICLE_COUNT, NBODY_MAGIC, NBODY_VERSION, ParticleSystem,  # noqa: F401,E402
                      Serializer, SimulationState)
+from . import cli, observability  # noqa: F401,E402

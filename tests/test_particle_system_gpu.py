@@ -98,3 +98,30 @@ def test_set_force_method_parameters_and_energy(nb, ctx):
     u = nb.ParticleSystem()
     u.update(0.1)
     assert u.computeKineticEnergy() == 0.0 and u.getSimulationTime() == 0.0
+
+
+# src/main.cpp:335-416: `nbody_sim --benchmark` headless loop, with export/import of a checkpoint
+@pytest.mark.parametrize("method", ["direct-n2", "barnes-hut", "spatial-hash"])
+def test_headless_benchmark_mode(nb, ctx, tmp_path, method):
+    import io
+    import json
+    out_json, ck = tmp_path / "bench.json", tmp_path / "state.nbody"
+    buf = io.StringIO()
+    o = nb.cli.parseAppCliOptions(["nbody_sim", "--particles", "4096", "--method", method, "--benchmark-steps", "5",
+                                   "--benchmark-output", str(out_json), "--export", str(ck), "--softening", "0.05"])
+    assert nb.cli.runBenchmarkMode(o, out=buf) == 0
+    doc = json.loads(out_json.read_text())["benchmarks"][0]
+    assert doc["benchmark_name"] == "application.benchmark_mode" and doc["particle_count"] == 4096
+    assert doc["force_method"] == method.replace("-", "_") and doc["iterations"] == 5
+    assert doc["metrics"]["wall_time_ms"] > 0 and doc["metrics"]["steps_per_s"] > 0
+    assert doc["phase_timings"][0]["name"] == "simulation.update" and doc["phase_timings"][0]["samples"] == 5
+    assert doc["parameters"]["softening"] == pytest.approx(0.05)
+    st = nb.Serializer.load(str(ck))
+    assert st.particle_count == 4096 and st.simulation_time == pytest.approx(5 * 0.001, rel=1e-4)
+    # and back in through --import
+    o2 = nb.cli.parseAppCliOptions(["nbody_sim", "--particles", "16", "--method", method, "--benchmark-steps", "1",
+                                    "--import", str(ck)])
+    buf2 = io.StringIO()
+    assert nb.cli.runBenchmarkMode(o2, out=buf2) == 0
+    assert "Imported 4096 particles" in buf2.getvalue()
+    assert json.loads(buf2.getvalue().strip().splitlines()[-1])["benchmarks"][0]["particle_count"] == 4096
