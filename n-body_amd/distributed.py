@@ -134,6 +134,7 @@ class ShardedDirectSystem:
         assert mode in ("pair", "gather")
         self.mode = mode
         self.contrib = None
+        self._use_reduce_scatter = None
         n = int(ic["pos_x"].size)
         self.n = n
         self.S, self.lo, self.hi = shard_bounds(n, self.world, self.rank)
@@ -182,11 +183,16 @@ class ShardedDirectSystem:
         for i0, i1, sh, j0, j1 in pair_schedule(W, r, S):
             b.forces_pair(self.posm[i0:i1], self.posm_all[sh * S + j0:sh * S + j1], self.G, self.eps2,
                           mine[i0:i1], c[sh * S + j0:sh * S + j1], True, False)
-        if dist.get_backend(self.group) == "gloo":   # gloo has no reduce_scatter: all-reduce + slice
-            dist.all_reduce(c, group=self.group)
-            out.copy_(mine)
-        else:
-            dist.reduce_scatter_tensor(out, c, op=dist.ReduceOp.SUM, group=self.group)
+        if self._use_reduce_scatter is None:
+            self._use_reduce_scatter = dist.get_backend(self.group) != "gloo"  # gloo has none
+        if self._use_reduce_scatter:
+            try:
+                dist.reduce_scatter_tensor(out, c, op=dist.ReduceOp.SUM, group=self.group)
+                return
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self._use_reduce_scatter = False  # every rank runs the same build: all fall back alike
+        dist.all_reduce(c, group=self.group)       # all-reduce + slice: 2x the bytes, same result
+        out.copy_(mine)
 
     def initial_forces(self):
         """ref: ParticleSystem::initialize evaluates a(0) once (particle_system.cpp:88-91)."""

@@ -244,9 +244,13 @@ def test_full_size_properties(nb, oracle, ctx):
 
 # the symmetric (action = -reaction) kernel at sizes where it is the default, all register
 # blockings, ragged N (padding inside the last superblock), even and odd superblock counts
+@pytest.mark.parametrize("equal_mass", [True, False])
 @pytest.mark.parametrize("n,tpl", [(33000, 0), (40000, 2), (50001, 4), (70000, 6), (100003, 8), (65536, 0)])
-def test_symmetric_kernel_vs_oracle(nb, oracle, ctx, n, tpl):
+def test_symmetric_kernel_vs_oracle(nb, oracle, ctx, n, tpl, equal_mass):
     ic = nb.ic.plummer(n, seed=n)
+    if not equal_mass:  # the general-mass instantiation (the equal-mass one exits on the device flag)
+        ic["mass"] = (ic["mass"] * np.random.default_rng(n).uniform(0.2, 3.0, n)).astype(np.float32)
+        ic["mass"][::97] = 0.0
     p = packed(ic)
     eps2 = 1e-6
     try:
@@ -268,8 +272,13 @@ def test_symmetric_kernel_vs_oracle(nb, oracle, ctx, n, tpl):
 
 
 # two disjoint sets, every pair once: action on a, reaction on b
-def test_pair_kernel(nb, oracle, ctx):
+@pytest.mark.parametrize("masses", ["equal", "a_differs", "random"])
+def test_pair_kernel(nb, oracle, ctx, masses):
     ic = nb.ic.plummer(9000, seed=77)
+    if masses == "a_differs":
+        ic["mass"][:300] *= np.float32(2.0)
+    elif masses == "random":
+        ic["mass"] = (ic["mass"] * np.random.default_rng(5).uniform(0.5, 2.0, 9000)).astype(np.float32)
     p = packed(ic)
     for na in (4000, 5000, 257, 8743):
         a, b = p[:na].contiguous(), p[na:].contiguous()
