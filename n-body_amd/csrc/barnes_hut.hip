@@ -96,14 +96,21 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const float4* __restrict
   if (k < n) out[k] = posm[idx[k]];
 }
 
+// 32-byte traversal record: one s_load_dwordx8 per node, eight siblings = 256 contiguous bytes
+struct __attribute__((aligned(32))) NodeRec {
+  float cx, cy, cz, mass;  // centre of mass, mass
+  float size2;             // (2 half)^2
+  int first, count;        // range of the Morton-sorted body list
+  unsigned int child;      // first child id | child count << 28 ; 0 = leaf
+};
+
 // Per-node build records (SoA)
 struct TreeArrays {
   int* first;       // first sorted body
   int* last;        // one past the last sorted body
   int* child0;      // id of the first child, -1 = leaf
   int* child_last;  // id of the last child
-  float4* a;        // {com x, y, z, mass}                                   (traversal)
-  int4* b;          // {(2 half)^2 bits, first, count, child0 | nchild << 28} (traversal)
+  NodeRec* rec;     // 32-byte traversal record
   double4* m;       // fp64 monopole {com x, y, z, mass}
 };
 
@@ -200,11 +207,14 @@ __global__ __launch_bounds__(kBlock) void level_monopole_kernel(int level,
                       : make_double4(0.0, 0.0, 0.0, 0.0);
     }
     t.m[nid] = mono;
-    t.a[nid] = make_float4((float)mono.x, (float)mono.y, (float)mono.z, (float)mono.w);
     const float h = ldexpf(root->half, -level);
     const float size = 2.0f * h;  // :168
-    t.b[nid] = make_int4(__float_as_int(size * size), first, cnt,
-                         c0 < 0 ? 0 : (int)((unsigned)c0 | ((unsigned)nchild << 28)));
+    NodeRec r;
+    r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
+    r.size2 = size * size;
+    r.first = first; r.count = cnt;
+    r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)nchild << 28));
+    t.rec[nid] = r;
   }
 }
 
@@ -216,10 +226,10 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // ---------------------------------------------------------------------------------------
 template <bool GUARD>
 __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
-    const float4* __restrict__ node_a, const int4* __restrict__ node_b,
-    const float4* __restrict__ sorted, const int* __restrict__ idx, int n, float theta2,
-    float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
-    float* __restrict__ acc_z, unsigned long long* __restrict__ visit_count) {
+    const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
+    const int* __restrict__ idx, int n, float theta2, float eps2, float G,
+    float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
+    unsigned long long* __restrict__ visit_count) {
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[4][kStack];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -242,17 +252,22 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const int c0 = rfl(e.x), cn = rfl(e.y);
     const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.w) << 32) | (unsigned)rfl(e.z);
     const bool in = (M >> lane) & 1ull;
+    // the whole sibling group (<= 8 consecutive 32-byte records) is fetched up front with
+    // wave-uniform (scalar-cache) loads: ONE memory round trip per group instead of one per node.
+    // The node array is padded by 8 records, so reading past a short group is harmless.
+    NodeRec rec[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) rec[k] = nodes[c0 + k];
+    visited += cn;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int c = c0; c < c0 + cn; c++) {
-      const float4 A = node_a[c];  // wave-uniform address: scalar-cache loads
-      const int4 B = node_b[c];
-      visited++;
-      if (A.w == 0.0f) continue;   // :161-162 massless node
-      const int first = B.y, cnt = B.z;
-      const unsigned int ci = (unsigned int)B.w;
-      if (ci == 0u) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k >= cn) break;  // wave-uniform
+      const NodeRec nd = rec[k];
+      if (nd.mass == 0.0f) continue;   // :161-162 massless node
+      if (nd.child == 0u) {
         // leaf: its bodies interact individually (exact), the body itself is skipped (:175)
-        for (int q = first; q < first + cnt; q++) {
+        for (int q = nd.first; q < nd.first + nd.count; q++) {
           const float4 s = sorted[q];
           const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
           const float d2 = dx * dx + dy * dy + dz * dz;
@@ -264,19 +279,20 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
         }
         continue;
       }
-      const float dx = A.x - pi.x, dy = A.y - pi.y, dz = A.z - pi.z;
+      const float dx = nd.cx - pi.x, dy = nd.cy - pi.y, dz = nd.cz - pi.z;
       const float dist2 = dx * dx + dy * dy + dz * dz + eps2;  // :165
-      const float size2 = __int_as_float(B.x);
-      const bool accept = in && (size2 / dist2 < theta2);       // :171-172
+      // :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the same
+      // inequality without the IEEE division sequence; the oracle uses the same form
+      const bool accept = in && (nd.size2 < theta2 * dist2);
       if (accept) {
         const float inv = __builtin_amdgcn_rsqf(dist2);
-        const float f = (A.w * inv) * (inv * inv);
+        const float f = (nd.mass * inv) * (inv * inv);
         ax += f * dx; ay += f * dy; az += f * dz;
       }
       const unsigned long long O = __ballot(in && !accept);
       if (O != 0ull) {
         if (lane == 0)
-          stk[w][sp] = make_int4((int)(ci & 0x0fffffffu), (int)(ci >> 28),
+          stk[w][sp] = make_int4((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28),
                                  (int)(unsigned)(O & 0xffffffffull), (int)(unsigned)(O >> 32));
         sp++;
       }
@@ -328,7 +344,7 @@ static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                   g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl, g->d_nid[0], g->d_nid[1],
-                  g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.a, g->t.b, g->t.m,
+                  g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m,
                   g->d_tmp, g->d_visits};
   for (void* p : ptrs) (void)hipFree(p);
   delete g;
@@ -340,7 +356,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 }
 
 static int tree_alloc_nodes(nbody_hip_tree* g) {
-  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.a, g->t.b, g->t.m};
+  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m};
   for (void* p : ptrs) (void)hipFree(p);
   g->t = TreeArrays{};
   const size_t n = g->max_particles;
@@ -352,8 +368,8 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   if (e == hipSuccess) e = dmalloc(&g->t.last, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.child0, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.child_last, cap);
-  if (e == hipSuccess) e = dmalloc(&g->t.a, cap);
-  if (e == hipSuccess) e = dmalloc(&g->t.b, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.rec, cap + 8);  // + 8: sibling-group prefetch reads ahead
+  if (e == hipSuccess) e = hipMemset(g->t.rec, 0, (cap + 8) * sizeof(NodeRec));
   if (e == hipSuccess) e = dmalloc(&g->t.m, cap);
   if (e != hipSuccess)
     return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
@@ -497,13 +513,13 @@ extern "C" int nbody_hip_tree_compute_forces(nbody_hip_tree* g, nbody_particle_d
   const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
   NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), ctx->stream));
   if (eps2 < 1e-12f)
-    hipLaunchKernelGGL(bh_traverse_kernel<true>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.a,
-                       g->t.b, g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y,
-                       d->acc_z, g->d_visits);
+    hipLaunchKernelGGL(bh_traverse_kernel<true>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.rec,
+                       g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y, d->acc_z,
+                       g->d_visits);
   else
-    hipLaunchKernelGGL(bh_traverse_kernel<false>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.a,
-                       g->t.b, g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y,
-                       d->acc_z, g->d_visits);
+    hipLaunchKernelGGL(bh_traverse_kernel<false>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.rec,
+                       g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y, d->acc_z,
+                       g->d_visits);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
@@ -522,9 +538,9 @@ extern "C" int nbody_hip_tree_stats(nbody_hip_tree* g, int* node_count, float* r
   if (level_base_out)
     for (int k = 0; k < 12; k++) level_base_out[k] = k <= g->max_depth + 1 ? lb[k] : lb[g->max_depth + 1];
   if (root_mass) {
-    float4 a;
-    NBH_HIP(hipMemcpy(&a, g->t.a, sizeof(a), hipMemcpyDeviceToHost));
-    *root_mass = a.w;
+    NodeRec r;
+    NBH_HIP(hipMemcpy(&r, g->t.rec, sizeof(r), hipMemcpyDeviceToHost));
+    *root_mass = r.mass;
   }
   if (nodes_visited_per_wave_total)
     NBH_HIP(hipMemcpy(nodes_visited_per_wave_total, g->d_visits, sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -549,13 +565,11 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
   if (!host_nodes) return NBODY_HIP_OK;
   if (capacity_nodes < count)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "node buffer too small: %d < %d", capacity_nodes, count);
-  std::vector<float4> a(count);
-  std::vector<int4> b(count);
+  std::vector<NodeRec> rec(count);
   std::vector<unsigned int> keys(n);
   std::vector<int> idx(n);
   TreeRoot root;
-  NBH_HIP(hipMemcpy(a.data(), g->t.a, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost));
-  NBH_HIP(hipMemcpy(b.data(), g->t.b, (size_t)count * sizeof(int4), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(rec.data(), g->t.rec, (size_t)count * sizeof(NodeRec), hipMemcpyDeviceToHost));
   NBH_HIP(hipMemcpy(keys.data(), g->d_keys_b, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost));
   NBH_HIP(hipMemcpy(idx.data(), g->d_idx_b, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   NBH_HIP(hipMemcpy(&root, g->d_root, sizeof(root), hipMemcpyDeviceToHost));
@@ -564,8 +578,8 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
   for (int nid = 0; nid < count; nid++) {
     while (level < g->max_depth && nid >= lb[level + 1]) level++;
     RefOctreeNode& o = out[nid];
-    const int first = b[nid].y, cnt = b[nid].z;
-    const unsigned int ci = (unsigned int)b[nid].w;
+    const int first = rec[nid].first, cnt = rec[nid].count;
+    const unsigned int ci = rec[nid].child;
     const unsigned int k = keys[first];
     unsigned int q[3] = {0, 0, 0};
     for (int bit = 0; bit < 10; bit++) {
@@ -577,8 +591,8 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
     for (int ax = 0; ax < 3; ax++)
       o.center[ax] = root.lo[ax] + ((float)(q[ax] >> (10 - level)) + 0.5f) * (2.0f * h);
     o.half_size = h;
-    o.com[0] = a[nid].x; o.com[1] = a[nid].y; o.com[2] = a[nid].z;
-    o.total_mass = a[nid].w;
+    o.com[0] = rec[nid].cx; o.com[1] = rec[nid].cy; o.com[2] = rec[nid].cz;
+    o.total_mass = rec[nid].mass;
     for (int c = 0; c < 8; c++) o.children[c] = -1;
     o.is_leaf = ci == 0u;
     o.particle_index = (o.is_leaf && cnt >= 1) ? idx[first] : -1;
@@ -586,7 +600,7 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
     if (!o.is_leaf) {
       const int c0 = (int)(ci & 0x0fffffffu), nc = (int)(ci >> 28);
       const int shift = 27 - 3 * level;
-      for (int c = c0; c < c0 + nc; c++) o.children[(keys[b[c].y] >> shift) & 7u] = c;
+      for (int c = c0; c < c0 + nc; c++) o.children[(keys[rec[c].first] >> shift) & 7u] = c;
     }
   }
   return NBODY_HIP_OK;

@@ -670,7 +670,10 @@ ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y
       float dist2 = dx * dx + dy * dy + dz * dz + eps2; /* :165 */
       float size = 2.0f * nd->half;
       float size2 = size * size;                         /* :168 */
-      if (size2 / dist2 < theta2) {                      /* :171-172 */
+      /* :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the
+       * same inequality without a division; the HIP traversal uses the same form, so that both
+       * sides take identical decisions */
+      if (size2 < theta2 * dist2) {
         float inv = 1.0f / sqrtf(dist2);
         float f = G * (float)nd->mass * (inv * inv * inv);
         a0 += (double)(f * dx); a1 += (double)(f * dy); a2 += (double)(f * dz);
