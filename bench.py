@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane override")
     ap.add_argument("--splits", type=int, default=0, help="source splits override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["direct", "hash", "bh"], default="direct",
+                    help="direct = the headline metric (default); hash = BASELINE config 5 (N=4,194,304 "
+                         "uniform box, spatial hash, z-slab shards + halo exchange); bh = config 4 "
+                         "(N=1,048,576 two-galaxy, Barnes-Hut theta 0.5, one GPU).  hash/bh report steps/s")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU (RCCL) code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
@@ -130,6 +134,66 @@ def read_pmc_traffic():
         return None
 
 
+def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
+    """BASELINE configs 4 and 5: steps/s of a full Velocity-Verlet step (not the headline metric)."""
+    from nbody_amd.distributed import HipBackend, ShardedHashSystem
+    dt = a.dt
+    if a.workload == "hash":
+        n = a.n if a.n != (1 << 20) else 4194304
+        half = 0.5 * (n / 16.0) ** (1.0 / 3.0)  # 16 bodies per unit volume (SURVEY 8d config 5)
+        ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
+        cell, cutoff, eps = 1.0, 1.0, 0.01
+        if sharded:
+            sysm = ShardedHashSystem(ic, 1.0, eps, cell, cutoff, backend=HipBackend(ctx))
+            sysm.initial_forces()
+            step = lambda: sysm.step(dt)  # noqa: E731
+            path = "z-slab shards, all-reduce bbox, all-to-all migration + halo per step"
+        else:
+            ps = nb.ParticleSystem()
+            ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod.SPATIAL_HASH, dt=dt,
+                                              softening=eps, spatial_hash_cell_size=cell,
+                                              spatial_hash_cutoff=cutoff), initial_conditions=ic)
+            step = lambda: ps.update(dt)  # noqa: E731
+            path = "ParticleSystem(SPATIAL_HASH)"
+        name = f"uniform_box_N{n}_spatial_hash_cell1_cutoff1_velocity_verlet"
+    else:
+        if sharded and world > 1:
+            raise SystemExit("Barnes-Hut is single-GPU (replicas only, DESIGN.md section 5)")
+        n = a.n
+        ic = nb.ic.two_galaxies(n, seed=42)
+        ic["mass"] = (ic["mass"] / np.float32(n)).astype(np.float32)
+        ps = nb.ParticleSystem()
+        ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod.BARNES_HUT, dt=dt,
+                                          softening=0.1, barnes_hut_theta=0.5), initial_conditions=ic)
+        step = lambda: ps.update(dt)  # noqa: E731
+        path = "ParticleSystem(BARNES_HUT, theta 0.5)"
+        name = f"two_galaxies_N{n}_barnes_hut_theta0.5_velocity_verlet"
+
+    def barrier():
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if sharded:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    return {"metric": "steps_per_s", "value": a.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": name, "bodies": n, "dt": dt, "path": path}}
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE JSON line: RCCL prints a version banner to stdout when its first
@@ -164,8 +228,17 @@ def main():
         ctx.tuning(a.variant, a.tpl, a.splits)
 
     n = a.n
-    ic = nb.ic.plummer(n, seed=42)  # every rank builds the same bodies, keeps its shard
     G, eps, dt = 1.0, a.eps, a.dt
+    if a.workload != "direct":
+        out = run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch)
+        if sharded:
+            dist.barrier()
+            dist.destroy_process_group()
+        if out is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        return
+    ic = nb.ic.plummer(n, seed=42)  # every rank builds the same bodies, keeps its shard
 
     def barrier():
         if sharded:
