@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="total bodies (default 1,048,576)")
+    ap.add_argument("--bodies", dest="n", type=int, default=1 << 20,
+                    help="total bodies (default 1,048,576; not --n: torch.distributed.run treats that as an "
+                         "ambiguous abbreviation of its own options)")
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant override (experiments)")

@@ -60,3 +60,27 @@ def test_reference_example_force_methods(tmp_path):
     assert r.returncode == 0, out[-2000:] + r.stderr[-2000:]
     for name in ("Direct N", "Barnes-Hut", "Spatial Hash", "Performance Scaling", "20000"):
         assert name in out
+
+
+# the multi-GPU code paths (process group, RCCL all-gather, barrier, all-reduce) with ONE rank
+# under torch.distributed.run: everything except the cross-rank traffic itself
+@pytest.mark.parametrize("workload,n", [("direct", 65536), ("hash", 131072)])
+def test_sharded_bench_rehearsal_one_rank(workload, n):
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline",
+           "--workload", workload, "--bodies", str(n), "--kernel-iters", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line on stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 1 and doc["value"] > 0 and doc["steps"] == 2
+    if workload == "direct":
+        assert doc["metric"] == "pair_interactions_per_s" and "roofline" in doc

@@ -34,7 +34,9 @@ def main():
         ic["mass"] = (ic["mass"] / np.float32(n)).astype(np.float32)
     print(f"ic={which}", flush=True)
     d, _ = to_device(nb, ic)
-    calc = nb.BarnesHutCalculator(theta)
+    method = os.environ.get("NBODY_METHOD", "bh")
+    calc = nb.DirectForceCalculator() if method == "direct" else nb.BarnesHutCalculator(theta)
+    print(f"method={method}", flush=True)
     calc.setGravitationalConstant(G)
     calc.setSofteningParameter(eps)
     integ = nb.Integrator()
