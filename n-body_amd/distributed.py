@@ -307,19 +307,37 @@ class ShardedHashSystem:
 
     # -- variable-size exchange: rows of `tensors` selected by `dest` go to their rank -----------
     def _exchange(self, tensors, dest):
+        """All tensors travel as ONE packed float32 matrix (integer columns bit-cast), so an exchange
+        is two collectives: the counts and the rows."""
         W = self.world
+        cols, kinds = [], []
+        for t in tensors:
+            if t.dtype == torch.float32:
+                c = t.reshape(t.shape[0], -1)
+            elif t.dtype == torch.int64:
+                c = t.to(torch.int32).view(torch.float32).reshape(t.shape[0], 1)  # ids < 2^31
+            else:
+                raise TypeError(t.dtype)
+            cols.append(c)
+            kinds.append((t.dtype, t.shape[1:], c.shape[1]))
+        packed = torch.cat(cols, 1) if len(cols) > 1 else cols[0]
         order = torch.argsort(dest, stable=True)
         counts = torch.bincount(dest, minlength=W).to(torch.int64)
         recv_counts = torch.empty_like(counts)
         dist.all_to_all_single(recv_counts, counts, group=self.group)
         send_split, recv_split = counts.tolist(), recv_counts.tolist()
-        out = []
-        for t in tensors:
-            src = t.index_select(0, order).contiguous()
-            dst = torch.empty((sum(recv_split),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_to_all_single(dst, src, output_split_sizes=recv_split,
-                                   input_split_sizes=send_split, group=self.group)
-            out.append(dst)
+        src = packed.index_select(0, order).contiguous()
+        dst = torch.empty((sum(recv_split), packed.shape[1]), dtype=torch.float32, device=packed.device)
+        dist.all_to_all_single(dst, src, output_split_sizes=recv_split, input_split_sizes=send_split,
+                               group=self.group)
+        out, c0 = [], 0
+        for dtype, tail, width in kinds:
+            piece = dst[:, c0:c0 + width]
+            c0 += width
+            if dtype == torch.int64:
+                out.append(piece.contiguous().view(torch.int32).reshape(-1).to(torch.int64))
+            else:
+                out.append(piece.reshape((dst.shape[0],) + tuple(tail)).contiguous())
         return out
 
     def compute_forces(self):
