@@ -213,3 +213,31 @@ def test_leaf_max_variant(nb, oracle, ctx):
                                  float(np.float32(0.01) ** 2), 0.5, 10, 8)
     assert rel_err(a, np.stack(r[:3], 1)).max() < TOL
     assert tree.getNodeCount() == r[4]
+
+
+# BASELINE config 4 at full size (N = 1,048,576 two-galaxy, theta = 0.5): size-independent checks
+def test_full_size_two_galaxies(nb, oracle, ctx):
+    n = 1 << 20
+    ic = nb.ic.two_galaxies(n, seed=42)
+    ic["mass"] = (ic["mass"] / np.float32(n)).astype(np.float32)
+    d, h = to_device(nb, ic)
+    calc = nb.BarnesHutCalculator(0.5)
+    calc.setSofteningParameter(0.1)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert np.all(np.isfinite(a))
+    tree = calc.getTree()
+    st = tree.stats()
+    assert abs(st["root_mass"] - 1.0) < 1e-3 and tree.verifyMassConservation(h)   # :511-519
+    assert n < st["node_count"] < 3 * n
+    # sampled bodies against the exact sum (oracle, fp64-accumulated): the theta = 0.5 contract
+    idx = np.linspace(0, n - 1, 96).astype(np.int64)
+    ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
+                                                1.0, float(np.float32(0.1) ** 2), 1), 1)
+    e = rel_err(a[idx], ref)
+    assert np.median(e) < 0.01 and e.max() < 0.10
+    # theta = 0 on the same tree is the exact sum
+    tree.computeForces(d, 0.0, 1.0, 0.1)
+    assert rel_err(acc_of(d)[idx], ref).max() < TOL
+    calc.computeForces(d)
+    assert np.array_equal(acc_of(d), a)  # reproducible

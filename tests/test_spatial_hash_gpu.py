@@ -214,3 +214,23 @@ def test_packed_slabs_equal_whole(nb, oracle, ctx, cutoff):
     gid, pos, vel, acc = sysm.gather_global()
     assert np.allclose(pos[:, 0], d.pos_x.cpu().numpy(), rtol=1e-6, atol=1e-6)
     assert np.allclose(vel[:, 1], d.vel_y.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+# BASELINE config 5 at full size on one GPU (N = 4,194,304, 16 bodies per unit volume)
+def test_full_size_uniform_box(nb, oracle, ctx):
+    n, half = 4194304, 32.0
+    ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(1.0, 1.0)
+    calc.setSofteningParameter(0.01)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert np.all(np.isfinite(a))
+    g = calc.getGrid()
+    assert g.getGridDims() == (66, 66, 66) or g.getGridDims() == (65, 65, 65)
+    idx = np.linspace(0, n - 1, 192).astype(np.int64)
+    dc = np.stack(oracle.direct_cutoff_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx, 1.0,
+                                              float(np.float32(0.01) ** 2), 1.0), 1)
+    assert rel_err(a[idx], dc).max() < TOL
+    # short-range forces of a uniform medium cancel on average: the mean is far below the rms
+    assert np.abs(a.mean(0)).max() < 0.02 * a.std(0).min()
