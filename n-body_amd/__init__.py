@@ -9,7 +9,8 @@ from ._lib import (DeviceException, NBodyError, ResourceException, StateExceptio
                    ValidationException)
 from .api import *  # noqa: F401,F403
 from .api import (BarnesHutCalculator, BarnesHutTree, Context, DirectForceCalculator, ForceCalculator, ForceMethod,  # noqa: F401
-                  InitDistribution, Integrator, ParticleData, ParticleDataManager,
+                  InitDistribution, Integrator, ParticleData, ParticleDataManager, ParticleInitializer,
+                  DiskDistParams, SphericalDistParams, UniformDistParams,
                   SimulationConfig, SpatialHashCalculator, SpatialHashGrid,
                   createForceCalculator, default_context,
                   direct_forces_pair_packed, direct_forces_packed, pack_posm,

@@ -246,6 +246,114 @@ class ParticleDataManager:
             getattr(h_data, f)[:n] = getattr(d_data, f)[:n].cpu().numpy()
 
 
+# ---- host initialisers ------------------------------------------------------------------------
+
+@dataclass
+class UniformDistParams:  # types.hpp:330-335
+    min_bounds: tuple = (0.0, 0.0, 0.0)
+    max_bounds: tuple = (0.0, 0.0, 0.0)
+    min_mass: float = 1.0
+    max_mass: float = 1.0
+
+
+@dataclass
+class SphericalDistParams:  # types.hpp:346-351
+    center: tuple = (0.0, 0.0, 0.0)
+    radius: float = 10.0
+    min_mass: float = 1.0
+    max_mass: float = 1.0
+
+
+@dataclass
+class DiskDistParams:  # types.hpp:362-369
+    center: tuple = (0.0, 0.0, 0.0)
+    radius: float = 10.0
+    thickness: float = 1.0
+    min_mass: float = 1.0
+    max_mass: float = 1.0
+    rotation_speed: float = 1.0
+
+
+class _Mt19937Floats:
+    """std::mt19937(seed) feeding std::uniform_real_distribution<float> the way libstdc++ does
+    (bits/random.tcc generate_canonical<float,24>): one 32-bit draw x per variate,
+    u = float(x) / 2^32 (x rounded to nearest-even float; u >= 1 -> nextafter(1,0)), result
+    a + (b - a) * u in float32.  numpy's legacy RandomState(seed) is the same init_genrand stream."""
+
+    def __init__(self, seed: int):
+        self._bits = np.random.RandomState(seed)._bit_generator
+
+    def canonical(self, count: int) -> np.ndarray:
+        x = self._bits.random_raw(count).astype(np.uint32)
+        u = x.astype(np.float32) / np.float32(4294967296.0)
+        return np.minimum(u, np.nextafter(np.float32(1), np.float32(0)))
+
+
+def _dist(u, a, b):
+    a, b = np.float32(a), np.float32(b)
+    return u * (b - a) + a
+
+
+class ParticleInitializer:
+    """particle_data.hpp:38-57 / particle_init.cu:286-376: the three host recipes, drawing from the
+    generator in the reference's order (per body).  Bit-exact for the uniform box; the sphere and
+    disk go through cbrt / sin / cos / acos / sqrt, where numpy and glibc may differ in the last ulp
+    (tests/test_system_cpu.py compares with the C++ facade built on libstdc++)."""
+
+    @staticmethod
+    def zeroVelocities(h: ParticleData):
+        for f in ("vel_x", "vel_y", "vel_z"):
+            getattr(h, f)[:] = 0
+
+    @staticmethod
+    def zeroAccelerations(h: ParticleData):
+        for f in ("acc_x", "acc_y", "acc_z", "acc_old_x", "acc_old_y", "acc_old_z"):
+            getattr(h, f)[:] = 0
+
+    @staticmethod
+    def initUniform(h: ParticleData, p: UniformDistParams, seed: int = 42):
+        n = h.count
+        u = _Mt19937Floats(seed).canonical(4 * n).reshape(n, 4)  # per body: x, y, z, mass
+        for k, f in enumerate(("pos_x", "pos_y", "pos_z")):
+            getattr(h, f)[:] = _dist(u[:, k], p.min_bounds[k], p.max_bounds[k])
+        h.mass[:] = _dist(u[:, 3], p.min_mass, p.max_mass)
+        ParticleInitializer.zeroVelocities(h)
+        ParticleInitializer.zeroAccelerations(h)
+
+    @staticmethod
+    def initSpherical(h: ParticleData, p: SphericalDistParams, seed: int = 42):
+        n = h.count
+        f32 = np.float32
+        u = _Mt19937Floats(seed).canonical(4 * n).reshape(n, 4)  # radius, azimuth, polar, mass
+        r = np.cbrt(_dist(u[:, 0], 0, 1)) * f32(p.radius)
+        theta = _dist(u[:, 1], 0, 1) * f32(2.0) * f32(3.14159265)
+        phi = np.arccos(f32(2.0) * _dist(u[:, 2], 0, 1) - f32(1.0))
+        h.pos_x[:] = f32(p.center[0]) + r * np.sin(phi) * np.cos(theta)
+        h.pos_y[:] = f32(p.center[1]) + r * np.sin(phi) * np.sin(theta)
+        h.pos_z[:] = f32(p.center[2]) + r * np.cos(phi)
+        h.mass[:] = _dist(u[:, 3], p.min_mass, p.max_mass)
+        ParticleInitializer.zeroVelocities(h)
+        ParticleInitializer.zeroAccelerations(h)
+
+    @staticmethod
+    def initDisk(h: ParticleData, p: DiskDistParams, seed: int = 42):
+        n = h.count
+        f32 = np.float32
+        u = _Mt19937Floats(seed).canonical(4 * n).reshape(n, 4)  # radius, azimuth, height, mass
+        r = np.sqrt(_dist(u[:, 0], 0, 1)) * f32(p.radius)
+        theta = _dist(u[:, 1], 0, 1) * f32(2.0) * f32(3.14159265)
+        z = (_dist(u[:, 2], 0, 1) - f32(0.5)) * f32(p.thickness)
+        h.pos_x[:] = f32(p.center[0]) + r * np.cos(theta)
+        h.pos_y[:] = f32(p.center[1]) + r * np.sin(theta)
+        h.pos_z[:] = f32(p.center[2]) + z
+        v = f32(p.rotation_speed) * np.sqrt(r)
+        h.vel_x[:] = -v * np.sin(theta)
+        h.vel_y[:] = v * np.cos(theta)
+        h.vel_z[:] = 0
+        h.mass[:] = _dist(u[:, 3], p.min_mass, p.max_mass)
+        ParticleInitializer.zeroAccelerations(h)
+
+
 # ---- force calculators -----------------------------------------------------------------------
 
 class ForceCalculator:

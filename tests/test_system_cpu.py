@@ -127,3 +127,34 @@ def test_checkpoint_round_trip_counts(nb, count):
         assert abs(getattr(back, k) - getattr(st, k)) < 1e-6
     for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass"):
         assert np.array_equal(getattr(back, k), getattr(st, k))
+
+
+# a12: the Python ParticleInitializer against the C++ facade's (libstdc++ mt19937 +
+# uniform_real_distribution<float>, i.e. what the reference's particle_init.cu:286-357 produces in
+# this toolchain).  Host-only program, no GPU needed.
+IC_DUMP = os.path.join(ROOT, "n-body_amd", "lib", "ic_dump")
+
+
+@pytest.mark.skipif(not os.path.exists(IC_DUMP), reason="facade not built")
+@pytest.mark.parametrize("kind,seed,n", [("uniform", 42, 1000), ("uniform", 7, 333), ("spherical", 42, 1000),
+                                         ("disk", 42, 1000), ("disk", 123, 77)])
+def test_initializers_match_cpp_facade(nb, tmp_path, kind, seed, n):
+    out = tmp_path / "ic.bin"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(IC_DUMP) + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    subprocess.run([IC_DUMP, kind, str(n), str(seed), str(out)], check=True, env=env)
+    ref = np.fromfile(out, dtype=np.float32).reshape(7, n)
+    h = nb.ParticleData()
+    nb.ParticleDataManager.allocateHost(h, n)
+    if kind == "uniform":
+        nb.ParticleInitializer.initUniform(h, nb.UniformDistParams((-10, -5, -2.5), (10, 5, 7.5), 0.5, 2.0), seed)
+    elif kind == "spherical":
+        nb.ParticleInitializer.initSpherical(h, nb.SphericalDistParams((1, -2, 0.5), 10.0, 1.0, 3.0), seed)
+    else:
+        nb.ParticleInitializer.initDisk(h, nb.DiskDistParams((0.5, 0, -1), 10.0, 1.0, rotation_speed=0.5), seed)
+    got = np.stack([h.pos_x, h.pos_y, h.pos_z, h.vel_x, h.vel_y, h.vel_z, h.mass])
+    if kind == "uniform":
+        assert np.array_equal(got, ref)  # bit for bit
+    else:
+        assert np.array_equal(got[6], ref[6])  # masses: no transcendental involved
+        assert np.allclose(got, ref, rtol=0, atol=4e-6)  # a few ulp of |x| <= 11 through cbrt/sin/cos/acos
