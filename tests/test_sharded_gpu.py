@@ -1,0 +1,134 @@
+"""The N>1 paths with the real HIP backend: several ranks share the one GPU of the test box and
+talk over gloo (RCCL refuses two ranks on one device), so everything but the transport is the
+production path: HipBackend kernels (pair kernel, packed drift/kick, slab grids), the shard /
+schedule / exchange logic, stream ordering between collectives and kernels.  At most 4 ranks
+(the box allows 6 processes on the card)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(rank, world, port):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+
+
+def _direct_worker(rank, world, port, n, steps, mode, out_dir):
+    _setup(rank, world, port)
+    try:
+        import nbody_amd
+        from nbody_amd.distributed import HipBackend, ShardedDirectSystem
+        ic = nbody_amd.ic.plummer(n, seed=5)
+        ctx = nbody_amd.Context()
+        sysm = ShardedDirectSystem(ic, 1.0, 0.01, backend=HipBackend(ctx), mode=mode)
+        assert sysm.mode == mode and sysm.device.type == "cuda"
+        sysm.initial_forces()
+        for _ in range(steps):
+            sysm.step(1e-3)
+        pos, vel, acc = (sysm.gather_global(k) for k in ("posm", "vel", "acc"))
+        ke = sysm.kinetic_energy()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "d.npz"), pos=pos, vel=vel, acc=acc, ke=ke)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,mode", [(2, 40000, "pair"), (3, 40001, "pair"), (4, 70000, "pair"),
+                                          (2, 9000, "gather")])
+def test_sharded_direct_on_gpu(tmp_path, world, n, mode, oracle, nb):
+    from oracle_bind import host_state
+    steps = 2
+    mp.spawn(_direct_worker, args=(world, _free_port(), n, steps, mode, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "d.npz")
+    s = host_state(nb.ic.plummer(n, seed=5))
+    eps2 = float(np.float32(0.01) * np.float32(0.01))
+    s["acc_x"], s["acc_y"], s["acc_z"] = oracle.direct_forces(s["pos_x"], s["pos_y"], s["pos_z"],
+                                                              s["mass"], 1.0, eps2, 1)
+    oracle.integrate_direct(s, 1.0, 0.01, 1e-3, steps, 1)
+    ref = np.stack([s["acc_x"], s["acc_y"], s["acc_z"]], 1).astype(np.float64)
+    err = np.linalg.norm(got["acc"][:, :3] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 1e-5, err.max()   # north_star tolerance, per body
+    for col, k in enumerate(("pos_x", "pos_y", "pos_z")):
+        assert np.allclose(got["pos"][:, col], s[k], rtol=1e-6, atol=1e-6), k
+    assert np.array_equal(got["pos"][:, 3], s["mass"])
+    for col, k in enumerate(("vel_x", "vel_y", "vel_z")):
+        assert np.allclose(got["vel"][:, col], s[k], rtol=1e-5, atol=1e-6), k
+
+
+def _hash_worker(rank, world, port, n, steps, cutoff, out_dir):
+    _setup(rank, world, port)
+    try:
+        import nbody_amd
+        from nbody_amd.distributed import HipBackend, ShardedHashSystem
+        ic = nbody_amd.ic.uniform_box(n, seed=11, lo=-8.0, hi=8.0, min_mass=0.5, max_mass=1.5)
+        rng = np.random.default_rng(3)
+        for k in ("vel_x", "vel_y", "vel_z"):
+            ic[k] = rng.normal(0, 3.0, n).astype(np.float32)
+        sysm = ShardedHashSystem(ic, 1.0, 0.05, 1.0, cutoff, backend=HipBackend(nbody_amd.Context()))
+        sysm.initial_forces()
+        moved = 0
+        for _ in range(steps):
+            sysm.step(0.02)
+            moved += sysm.migrated
+        gid, pos, vel, acc = sysm.gather_global()
+        tot = torch.tensor([moved, sysm.halo_bodies], dtype=torch.int64)
+        dist.all_reduce(tot)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "h.npz"), gid=gid, pos=pos, vel=vel, acc=acc,
+                     moved=int(tot[0]), halo=int(tot[1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cutoff", [(2, 1.0), (3, 2.0)])
+def test_sharded_hash_on_gpu(tmp_path, world, cutoff, oracle, nb):
+    from oracle_bind import host_state
+    n, steps, dt, eps = 20000, 2, 0.02, 0.05
+    mp.spawn(_hash_worker, args=(world, _free_port(), n, steps, cutoff, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "h.npz")
+    assert np.array_equal(got["gid"], np.arange(n))
+    assert got["moved"] > 0 and got["halo"] > 0
+    ic = nb.ic.uniform_box(n, seed=11, lo=-8.0, hi=8.0, min_mass=0.5, max_mass=1.5)
+    rng = np.random.default_rng(3)
+    for k in ("vel_x", "vel_y", "vel_z"):
+        ic[k] = rng.normal(0, 3.0, n).astype(np.float32)
+    s = host_state(ic)
+    eps2 = float(np.float32(eps) * np.float32(eps))
+
+    def forces():
+        return oracle.spatial_hash_forces(s["pos_x"], s["pos_y"], s["pos_z"], s["mass"], 1.0, eps2, 1.0, cutoff)
+
+    s["acc_x"], s["acc_y"], s["acc_z"] = forces()
+    for _ in range(steps):
+        for k in ("x", "y", "z"):
+            s["acc_old_" + k] = s["acc_" + k].copy()
+        oracle.update_positions(s, dt)
+        s["acc_x"], s["acc_y"], s["acc_z"] = forces()
+        oracle.update_velocities(s, dt)
+    for col, k in enumerate(("pos_x", "pos_y", "pos_z")):
+        assert np.allclose(got["pos"][:, col], s[k], rtol=1e-6, atol=1e-6), k
+    ref = np.stack([s["acc_x"], s["acc_y"], s["acc_z"]], 1).astype(np.float64)
+    scale = max(1.0, np.abs(ref).max())  # close pairs at eps = 0.05 reach |a| of a few hundred
+    assert np.abs(got["acc"][:, :3] - ref).max() < 1e-5 * scale
+    # dv = dt/2 (a_old + a_new) per step inherits the 1e-5 * |a| force tolerance
+    for col, k in enumerate(("vel_x", "vel_y", "vel_z")):
+        assert np.allclose(got["vel"][:, col], s[k], rtol=1e-5, atol=1e-5 * scale * dt * steps + 1e-6), k
