@@ -94,6 +94,22 @@ NBODY_HIP_API int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream);
  * ref: CUDA_CHECK_KERNEL's debug-mode cudaDeviceSynchronize, error_handling.hpp:124-136 */
 NBODY_HIP_API int nbody_hip_ctx_synchronize(nbody_hip_ctx* ctx);
 
+/* ---- step graphs (MI355X-native addition; no reference counterpart) ------------------------
+ * Between capture_begin and capture_end every call made with this context is recorded into a
+ * hipGraph instead of being executed; graph_launch replays the recording `times` times on the
+ * context's stream (one host call for a whole run of steps).  Rules: run the same calls once
+ * eagerly first (workspaces are sized on first use and allocation is not capturable); the pointers
+ * and body count are baked into the recording; calls that return data to the host (energies,
+ * *_info, *_stats, download, the spatial-hash grid build) are not capturable and fail with
+ * NBODY_HIP_ERR_STATE, after which capture_end reports the failure and restores the context.
+ * Measured (profiles/r01_step_graph_probe.txt): replay == eager time per step on MI355X, the
+ * inter-kernel gaps being GPU-side; the gain is host CPU time, not step rate. */
+typedef struct nbody_hip_graph nbody_hip_graph;
+NBODY_HIP_API int nbody_hip_capture_begin(nbody_hip_ctx* ctx);
+NBODY_HIP_API int nbody_hip_capture_end(nbody_hip_ctx* ctx, nbody_hip_graph** out);
+NBODY_HIP_API int nbody_hip_graph_launch(nbody_hip_graph* graph, int times);
+NBODY_HIP_API int nbody_hip_graph_destroy(nbody_hip_graph* graph);
+
 /* ---- a11: particle memory (ref: ParticleDataManager, src/cuda/particle_init.cu:143-283) */
 
 /* ref: allocateDevice :143-168 -- 13 arrays of `count` floats, accelerations zeroed.
@@ -229,6 +245,11 @@ NBODY_HIP_API int nbody_hip_cell_z_packed(nbody_hip_ctx* ctx, const nbody_float4
  *          src/cuda/force_barnes_hut.cu:204-532, include/nbody/barnes_hut_tree.hpp:9-81) ---- */
 
 typedef struct nbody_hip_tree nbody_hip_tree;
+
+/* Tuning hook for measurements: number of replicas (power of two, <= 16) that share each wave's
+ * walk when there are few bodies, and the tree level at which the walk is divided; 0 = automatic.
+ * Results are deterministic for a given setting; different settings differ by fp rounding only. */
+NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int split_level);
 
 /* ref: BarnesHutTree(max_particles) :204-210 */
 NBODY_HIP_API int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, nbody_hip_tree** out);

@@ -8,7 +8,7 @@ from . import _lib, ic  # noqa: F401
 from ._lib import (DeviceException, NBodyError, ResourceException, StateException,  # noqa: F401
                    ValidationException)
 from .api import *  # noqa: F401,F403
-from .api import (BarnesHutCalculator, BarnesHutTree, Context, DirectForceCalculator, ForceCalculator, ForceMethod,  # noqa: F401
+from .api import (BarnesHutCalculator, BarnesHutTree, Context, StepGraph, DirectForceCalculator, ForceCalculator, ForceMethod,  # noqa: F401
                   InitDistribution, Integrator, ParticleData, ParticleDataManager, ParticleInitializer,
                   DiskDistParams, SphericalDistParams, UniformDistParams,
                   SimulationConfig, SpatialHashCalculator, SpatialHashGrid,

@@ -59,6 +59,10 @@ PROTOTYPES = {
     "nbody_hip_ctx_destroy": (C.c_int, [_P]),
     "nbody_hip_ctx_set_stream": (C.c_int, [_P, _P]),
     "nbody_hip_ctx_synchronize": (C.c_int, [_P]),
+    "nbody_hip_capture_begin": (C.c_int, [_P]),
+    "nbody_hip_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
+    "nbody_hip_graph_launch": (C.c_int, [_P, C.c_int]),
+    "nbody_hip_graph_destroy": (C.c_int, [_P]),
     "nbody_hip_particles_alloc": (C.c_int, [_PD, C.c_size_t]),
     "nbody_hip_particles_free": (C.c_int, [_PD]),
     "nbody_hip_particles_upload": (C.c_int, [_PD, _PD]),
@@ -96,6 +100,7 @@ PROTOTYPES = {
     "nbody_hip_tree_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nbody_hip_tree_destroy": (C.c_int, [_P]),
     "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),
+    "nbody_hip_tree_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_tree_build": (C.c_int, [_P, _PD]),
     "nbody_hip_tree_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
     "nbody_hip_tree_stats": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float),

@@ -137,6 +137,11 @@ class Context:
     def synchronize(self):
         check(self._lib.nbody_hip_ctx_synchronize(self._h))
 
+    def capture(self):
+        """`with ctx.capture() as rec: ...calls...` records the calls into rec.graph (a StepGraph)
+        instead of executing them (include/nbody_hip.h, "step graphs")."""
+        return _Capture(self)
+
     def tuning(self, variant=-1, targets_per_lane=0, source_splits=0):
         check(self._lib.nbody_hip_direct_tuning(self._h, variant, targets_per_lane, source_splits))
 
@@ -150,6 +155,46 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class StepGraph:
+    """A recorded sequence of launches (hipGraphExec); launch(k) replays it k times in order."""
+
+    def __init__(self, ctx: Context, handle):
+        self._ctx, self._h = ctx, handle
+
+    def launch(self, times: int = 1):
+        check(self._ctx._lib.nbody_hip_graph_launch(self._h, int(times)))
+
+    def close(self):
+        if self._h is not None and self._h.value and self._ctx._h.value:
+            self._ctx._lib.nbody_hip_graph_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Capture:
+    def __init__(self, ctx: Context):
+        self.ctx, self.graph = ctx, None
+
+    def __enter__(self):
+        check(self.ctx._lib.nbody_hip_capture_begin(self.ctx.handle))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        rc = self.ctx._lib.nbody_hip_capture_end(self.ctx.handle, C.byref(h))  # always restores the context
+        if et is None:
+            check(rc)
+            self.graph = StepGraph(self.ctx, h)
+        elif rc == 0:
+            self.ctx._lib.nbody_hip_graph_destroy(h)
+        return False
 
 
 _default_ctx: dict[int, Context] = {}
@@ -388,6 +433,10 @@ class ForceCalculator:
     def computeForces(self, d_particles: ParticleData):
         raise NotImplementedError
 
+    def _graph_key(self):
+        """everything a recorded step bakes in besides the arrays"""
+        return (self.G_, self.softening_eps_)
+
     def getMethod(self) -> ForceMethod:
         raise NotImplementedError
 
@@ -572,6 +621,10 @@ class BarnesHutTree:
 
     def setParams(self, max_depth: int = 10, leaf_max: int = 1):
         check(self.ctx._lib.nbody_hip_tree_set_params(self._h, max_depth, leaf_max))
+        self._params = (int(max_depth), int(leaf_max))
+
+    def tuning(self, replicas: int = 0, split_level: int = 0):
+        check(self.ctx._lib.nbody_hip_tree_tuning(self._h, replicas, split_level))
 
     def build(self, d_particles: ParticleData):
         s = d_particles.struct()
@@ -632,6 +685,9 @@ class BarnesHutCalculator(ForceCalculator):
         self.tree_.build(d_particles)
         self.tree_.computeForces(d_particles, self.theta_, self.G_, self.softening_eps_)
 
+    def _graph_key(self):
+        return (self.G_, self.softening_eps_, self.theta_, id(self.tree_), getattr(self.tree_, "_params", None))
+
     def getMethod(self):
         return ForceMethod.BARNES_HUT
 
@@ -691,10 +747,41 @@ class Integrator:
         force_calc.computeForces(d_particles)
         self.updateVelocities(d_particles, dt)
 
-    def integrate_steps(self, d_particles, force_calc: DirectForceCalculator, dt: float, steps: int):
-        s = d_particles.struct()
-        check(self.ctx._lib.nbody_hip_integrate_direct(
-            self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, steps))
+    def integrate_steps(self, d_particles, force_calc: ForceCalculator, dt: float, steps: int,
+                        graph: bool | None = None):
+        """`steps` Velocity-Verlet steps queued back to back.  With graph=True the first step runs
+        eagerly (it sizes the workspaces), the second is recorded into a hipGraph and the rest replay
+        it; the recording is reused while (arrays, count, dt, calculator parameters) stay the same.
+        Off by default: measured on MI355X (profiles/r01_step_graph_probe.txt) a replayed step takes
+        the same time as the eager one at every size -- the gaps between the small dependent kernels
+        are on the GPU side, not in the host's launch calls.  The spatial-hash step reads its grid
+        size back every build and always runs eagerly."""
+        if steps <= 0:
+            return
+        if graph is None:
+            graph = False
+        if graph and isinstance(force_calc, SpatialHashCalculator):
+            graph = False
+        if not graph:
+            if isinstance(force_calc, DirectForceCalculator):
+                s = d_particles.struct()
+                check(self.ctx._lib.nbody_hip_integrate_direct(
+                    self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, steps))
+            else:
+                for _ in range(steps):
+                    self.integrate(d_particles, force_calc, dt)
+            return
+        key = (d_particles.pos_x.data_ptr(), d_particles.count, float(dt), id(force_calc), force_calc._graph_key())
+        if getattr(self, "_graph_for", None) != key:
+            self._graph, self._graph_for = None, None
+            self.integrate(d_particles, force_calc, dt)  # eager: allocations happen here
+            steps -= 1
+            if steps == 0:
+                return
+            with self.ctx.capture() as rec:
+                self.integrate(d_particles, force_calc, dt)
+            self._graph, self._graph_for = rec.graph, key
+        self._graph.launch(steps)
 
     def updatePositions(self, d_particles, dt):
         s = d_particles.struct()

@@ -104,6 +104,7 @@ extern "C" int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx) {
   if (ctx->host_scalar) (void)hipHostFree(ctx->host_scalar);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
   delete ctx;
   return NBODY_HIP_OK;
 }
@@ -116,8 +117,77 @@ extern "C" int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream) {
 
 extern "C" int nbody_hip_ctx_synchronize(nbody_hip_ctx* ctx) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  NBH_NOT_CAPTURABLE(ctx, "nbody_hip_ctx_synchronize");
   NBH_HIP(hipSetDevice(ctx->device));
   NBH_HIP(hipStreamSynchronize(ctx->stream));
+  return NBODY_HIP_OK;
+}
+
+// ---- step graphs -------------------------------------------------------------------------
+
+struct nbody_hip_graph {
+  nbody_hip_ctx* ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int nbody_hip_capture_begin(nbody_hip_ctx* ctx) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (ctx->capturing) return NBH_FAIL(NBODY_HIP_ERR_STATE, "capture already in progress");
+  NBH_HIP(hipSetDevice(ctx->device));
+  // the null stream cannot be captured: record on a stream of our own, replay on the caller's
+  if (!ctx->capture_stream) NBH_HIP(hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking));
+  NBH_HIP(hipStreamSynchronize(ctx->stream));
+  NBH_HIP(hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeThreadLocal));
+  ctx->user_stream = ctx->stream;
+  ctx->stream = ctx->capture_stream;
+  ctx->capturing = true;
+  ctx->capture_failed = false;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_capture_end(nbody_hip_ctx* ctx, nbody_hip_graph** out) {
+  if (!ctx || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  *out = nullptr;
+  if (!ctx->capturing) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no capture in progress");
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(ctx->capture_stream, &graph);
+  ctx->stream = ctx->user_stream;
+  ctx->capturing = false;
+  if (e != hipSuccess || !graph || ctx->capture_failed) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "hipStreamEndCapture: %s (a call inside the capture was not capturable)",
+                    hipGetErrorString(e));
+  }
+  nbody_hip_graph* g = new nbody_hip_graph();
+  g->ctx = ctx;
+  g->graph = graph;
+  const hipError_t ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+  if (ei != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    delete g;
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(ei));
+  }
+  *out = g;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_graph_launch(nbody_hip_graph* g, int times) {
+  if (!g || !g->exec) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null graph");
+  if (g->ctx->capturing) return NBH_FAIL(NBODY_HIP_ERR_STATE, "graph launch inside a capture");
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  for (int i = 0; i < times; i++) NBH_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_graph_destroy(nbody_hip_graph* g) {
+  if (!g) return NBODY_HIP_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
   return NBODY_HIP_OK;
 }
 

@@ -40,6 +40,8 @@ namespace nbh {
 
 constexpr int kMaxDepth = 10;      // 30-bit Morton keys
 constexpr int kStack = 8 * (kMaxDepth + 2);
+constexpr int kSplitBudget = 262144;  // replicas * n of the split traversal (= 4096 waves)
+constexpr int kMaxReplicas = 16;
 
 struct TreeRoot {
   float lo[3];
@@ -114,69 +116,102 @@ struct TreeArrays {
   double4* m;       // fp64 monopole {com x, y, z, mass}
 };
 
-__device__ __forceinline__ bool is_head(const unsigned int* __restrict__ keys, int i, int shift) {
-  // shift == 30 (level 0): every 30-bit key has prefix 0 -> only body 0 opens the root
-  return i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift);
+// ---------------------------------------------------------------------------------------
+// Topology from the sorted keys alone, all levels at once.
+//
+// A node at level L is a run of bodies sharing the 3L-bit key prefix ("group") whose PARENT group
+// holds more than leaf_max bodies (force_barnes_hut.cu:197-209: a node is split while it holds
+// more than one body; counts shrink monotonically down a branch, so the parent test implies
+// every ancestor's).  Both facts are local in the sorted key list, so one kernel flags the first
+// body of every node of every level (flag[L * n + i]), ONE inclusive scan over the level-major
+// flag array numbers the nodes (ids ascend by level, then by key = octant order; the children of
+// a node are consecutive), and one kernel fills the ranges and child links from that scan.
+// ---------------------------------------------------------------------------------------
+
+// how many of the `cap` bodies on one side of body i (dir = -1 / +1) share its prefix (key >> sp)
+__device__ __forceinline__ int side_extent(const unsigned int* __restrict__ keys, int i, int dir,
+                                           int cap, unsigned int prefix, int sp) {
+  int lo = 0, hi = cap;  // the answer is in [lo, hi]; the predicate is monotone (sorted keys)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((keys[i + dir * mid] >> sp) == prefix) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 
-// level L, step 1: flag[i] = body i opens a node at this level
-__global__ __launch_bounds__(kBlock) void level_flag_kernel(const unsigned int* __restrict__ keys,
-                                                            int n, int level, int leaf_max,
-                                                            const int* __restrict__ nid_prev,
-                                                            TreeArrays t, int* __restrict__ flag) {
+__global__ __launch_bounds__(kBlock) void tree_flags_kernel(const unsigned int* __restrict__ keys,
+                                                            int n, int max_depth, int leaf_max,
+                                                            int* __restrict__ flag) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  bool open = true;
-  if (level > 0) {
-    const int p = nid_prev[i];
-    open = p >= 0 && (t.last[p] - t.first[p]) > leaf_max;  // parent is an internal node
+  const unsigned int k = keys[i];
+  // first body of its group at level L  <=>  (d >> (30 - 3L)) != 0; body 0 heads every level
+  const unsigned int d = i == 0 ? 0xffffffffu : (k ^ keys[i - 1]);
+  bool open = true;  // the parent group is an internal node (level 0 has no parent)
+  for (int L = 0; L <= max_depth; L++) {
+    const int shift = 30 - 3 * L;
+    if (L > 0 && open) {
+      const int sp = shift + 3;
+      const unsigned int prefix = k >> sp;
+      const int a = side_extent(keys, i, -1, min(i, leaf_max), prefix, sp);
+      int b = 0;
+      if (a < leaf_max) b = side_extent(keys, i, +1, min(n - 1 - i, leaf_max - a), prefix, sp);
+      open = a + b >= leaf_max;  // parent holds at least a + b + 1 > leaf_max bodies
+    }
+    flag[(size_t)L * n + i] = (open && (d >> shift) != 0u) ? 1 : 0;
   }
-  const int shift = 30 - 3 * level;
-  flag[i] = (open && is_head(keys, i, shift)) ? 1 : 0;
 }
 
-// level L, step 2: node ids from the inclusive scan; ranges and parent links
-__global__ __launch_bounds__(kBlock) void level_fill_kernel(const unsigned int* __restrict__ keys,
-                                                            int n, int level, int leaf_max,
-                                                            const int* __restrict__ nid_prev,
-                                                            const int* __restrict__ incl,
-                                                            TreeArrays t, int capacity,
-                                                            int* __restrict__ nid_cur,
-                                                            int* __restrict__ level_base) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const int base = level_base[level];
-  if (i == n - 1) level_base[level + 1] = min(base + incl[n - 1], capacity);
-  bool open = true;
-  int p = -1;
-  if (level > 0) {
-    p = nid_prev[i];
-    open = p >= 0 && (t.last[p] - t.first[p]) > leaf_max;
+__global__ __launch_bounds__(kBlock) void tree_fill_kernel(const unsigned int* __restrict__ keys,
+                                                           int n, int max_depth, int leaf_max,
+                                                           const int* __restrict__ flag,
+                                                           const int* __restrict__ incl,
+                                                           TreeArrays t, int capacity,
+                                                           int* __restrict__ level_base) {
+  const size_t total = (size_t)(max_depth + 1) * n;
+  const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= total) return;
+  const int L = (int)(e / n), i = (int)(e - (size_t)L * n);
+  if (i == 0) {  // ids of level L start where the scan of the levels above ended
+    level_base[L] = L == 0 ? 0 : min(incl[e - 1], capacity);
+    if (L == max_depth) level_base[L + 1] = min(incl[total - 1], capacity);
   }
-  int nid = -1;
-  if (open) {
-    nid = base + incl[i] - 1;
-    if (nid >= capacity) nid = -1;  // cannot happen with the capacity bound; never write past it
+  if (!flag[e]) return;
+  const int nid = incl[e] - 1;
+  if (nid >= capacity) return;  // cannot happen with the capacity bound; never write past it
+  const int shift = 30 - 3 * L;
+  // one past the last body of the group: first j > i with another prefix
+  int last = n;
+  if (L > 0) {
+    const unsigned int prefix = keys[i] >> shift;
+    int lo = i + 1, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((keys[mid] >> shift) == prefix) lo = mid + 1; else hi = mid;
+    }
+    last = lo;
   }
-  nid_cur[i] = nid;
-  if (nid < 0) return;
-  const int shift = 30 - 3 * level;
-  if (is_head(keys, i, shift)) t.first[nid] = i;
-  if (i == n - 1 || (keys[i + 1] >> shift) != (keys[i] >> shift)) t.last[nid] = i + 1;
-  if (p >= 0) {
-    if (i == t.first[p]) t.child0[p] = nid;
-    if (i + 1 == t.last[p]) t.child_last[p] = nid;
+  t.first[nid] = i;
+  t.last[nid] = last;
+  int c0 = -1, c1 = -1;
+  if (L < max_depth && last - i > leaf_max) {
+    // children: the flagged bodies of level L + 1 inside [i, last); body i is always one of them
+    const size_t ce = (size_t)(L + 1) * n;
+    c0 = incl[ce + i] - 1;
+    c1 = incl[ce + last - 1] - 1;
+    if (c1 >= capacity) { c0 = -1; c1 = -1; }
   }
+  t.child0[nid] = c0;
+  t.child_last[nid] = c1;
 }
 
 // monopoles of one level (deepest first) + the packed traversal records
-__global__ __launch_bounds__(kBlock) void level_monopole_kernel(int level,
-                                                                const int* __restrict__ level_base,
-                                                                const float4* __restrict__ sorted,
-                                                                const TreeRoot* __restrict__ root,
-                                                                TreeArrays t) {
+template <int BLOCK>
+__device__ __forceinline__ void monopole_level(int level, const int* __restrict__ level_base,
+                                               const float4* __restrict__ sorted,
+                                               const TreeRoot* __restrict__ root, TreeArrays t) {
   const int lo = level_base[level], hi = level_base[level + 1];
-  for (int nid = lo + blockIdx.x * kBlock + threadIdx.x; nid < hi; nid += gridDim.x * kBlock) {
+  for (int nid = lo + blockIdx.x * BLOCK + threadIdx.x; nid < hi; nid += gridDim.x * BLOCK) {
     const int first = t.first[nid], cnt = t.last[nid] - first;
     const int c0 = t.child0[nid];
     double mx = 0.0, my = 0.0, mz = 0.0, ms = 0.0;
@@ -218,21 +253,57 @@ __global__ __launch_bounds__(kBlock) void level_monopole_kernel(int level,
   }
 }
 
+__global__ __launch_bounds__(kBlock) void level_monopole_kernel(int level,
+                                                                const int* __restrict__ level_base,
+                                                                const float4* __restrict__ sorted,
+                                                                const TreeRoot* __restrict__ root,
+                                                                TreeArrays t) {
+  monopole_level<kBlock>(level, level_base, sorted, root, t);
+}
+
+// levels top_level .. 0 in ONE workgroup (a level reads the level below through global memory,
+// ordered by the block barrier): the upper levels hold at most 8^L nodes, and with few bodies
+// every level is small -- one launch instead of one per level.
+constexpr int kTopBlock = 1024;
+__global__ __launch_bounds__(kTopBlock) void top_monopole_kernel(int top_level,
+                                                                 const int* __restrict__ level_base,
+                                                                 const float4* __restrict__ sorted,
+                                                                 const TreeRoot* __restrict__ root,
+                                                                 TreeArrays t) {
+  for (int level = top_level; level >= 0; level--) {
+    monopole_level<kTopBlock>(level, level_base, sorted, root, t);
+    __threadfence_block();  // one workgroup = one CU: its writes are visible to its own waves
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------------------
 // Traversal.  block = 256 = 4 independent waves; wave w of block b walks the tree for sorted
 // bodies [b*256 + w*64, +64).
+//
+// SPLIT (few bodies): a walk is a chain of dependent node fetches, so its speed comes from having
+// many waves in flight -- with n / 64 waves below a few thousand the chip idles.  gridDim.y = K
+// replicas then share each wave's walk: nodes of the levels <= split level (ids < split_end,
+// "shared zone") are visited by every replica, but a node there contributes, and is descended
+// below the split level, only in the replica that owns it (id mod K); deeper nodes belong to the
+// replica that entered their subtree.  The replicas' fp64 partial sums are added in replica order
+// by bh_combine_kernel (deterministic).
 // ---------------------------------------------------------------------------------------
-template <bool GUARD>
+template <bool GUARD, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
     const int* __restrict__ idx, int n, float theta2, float eps2, float G,
     float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
-    unsigned long long* __restrict__ visit_count) {
+    unsigned long long* __restrict__ visit_count, const int* __restrict__ level_base, int split_level,
+    double* __restrict__ partial) {
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[4][kStack];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int replica = SPLIT ? (int)blockIdx.y : 0;
+  const int rmask = SPLIT ? (int)gridDim.y - 1 : 0;  // K is a power of two
+  const int split_end = SPLIT ? level_base[split_level + 1] : 0;
   const int t = blockIdx.x * kBlock + tid;
   const bool valid = t < n;
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -265,8 +336,28 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       if (k >= cn) break;  // wave-uniform
       const NodeRec nd = rec[k];
       if (nd.mass == 0.0f) continue;   // :161-162 massless node
+      bool mine = true, descend = true;  // wave-uniform
+      if (SPLIT && c0 + k < split_end) {
+        mine = ((c0 + k) & rmask) == replica;
+        descend = mine || (int)(nd.child & 0x0fffffffu) < split_end;
+      }
       if (nd.child == 0u) {
+        if (!mine) continue;
         // leaf: its bodies interact individually (exact), the body itself is skipped (:175)
+        if (SPLIT && nd.count == 1) {
+          // the record of a one-body leaf IS the body (the monopole pass copies x, y, z, m
+          // unchanged): no fetch from the body list, i.e. one dependent memory round trip less.
+          // Only in the latency-bound split walk: measured 10% faster there, 8-15% slower at 1M
+          // bodies, where the scalar fetch of the body overlaps with other waves.
+          const float dx = nd.cx - pi.x, dy = nd.cy - pi.y, dz = nd.cz - pi.z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+          bool ok = in && (nd.first != t);
+          if (GUARD) ok = ok && (d2 > 0.f);
+          const float f = ok ? (nd.mass * inv) * (inv * inv) : 0.f;
+          ax += f * dx; ay += f * dy; az += f * dz;
+          continue;
+        }
         for (int q = nd.first; q < nd.first + nd.count; q++) {
           const float4 s = sorted[q];
           const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
@@ -284,13 +375,13 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       // :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the same
       // inequality without the IEEE division sequence; the oracle uses the same form
       const bool accept = in && (nd.size2 < theta2 * dist2);
-      if (accept) {
+      if (accept && mine) {  // skipped by the whole wave when every lane opens the node (common)
         const float inv = __builtin_amdgcn_rsqf(dist2);
         const float f = (nd.mass * inv) * (inv * inv);
         ax += f * dx; ay += f * dy; az += f * dz;
       }
       const unsigned long long O = __ballot(in && !accept);
-      if (O != 0ull) {
+      if (O != 0ull && descend) {
         if (lane == 0)
           stk[w][sp] = make_int4((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28),
                                  (int)(unsigned)(O & 0xffffffffull), (int)(unsigned)(O >> 32));
@@ -301,12 +392,35 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     __builtin_amdgcn_wave_barrier();
   }
   if (valid) {
-    const int i = idx[t];
-    acc_x[i] = (float)((double)G * sx);
-    acc_y[i] = (float)((double)G * sy);
-    acc_z[i] = (float)((double)G * sz);
+    if (SPLIT) {
+      double* p = partial + (size_t)replica * 3 * n;
+      p[t] = sx; p[(size_t)n + t] = sy; p[2 * (size_t)n + t] = sz;
+    } else {
+      const int i = idx[t];
+      acc_x[i] = (float)((double)G * sx);
+      acc_y[i] = (float)((double)G * sy);
+      acc_z[i] = (float)((double)G * sz);
+    }
   }
   if (visit_count && lane == 0) atomicAdd(visit_count, visited);
+}
+
+__global__ __launch_bounds__(kBlock) void bh_combine_kernel(const double* __restrict__ partial, int replicas,
+                                                            const int* __restrict__ idx, int n, float G,
+                                                            float* __restrict__ acc_x,
+                                                            float* __restrict__ acc_y,
+                                                            float* __restrict__ acc_z) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int r = 0; r < replicas; r++) {
+    const double* p = partial + (size_t)r * 3 * n;
+    sx += p[t]; sy += p[(size_t)n + t]; sz += p[2 * (size_t)n + t];
+  }
+  const int i = idx[t];
+  acc_x[i] = (float)((double)G * sx);
+  acc_y[i] = (float)((double)G * sy);
+  acc_z[i] = (float)((double)G * sz);
 }
 
 }  // namespace nbh
@@ -332,20 +446,22 @@ struct nbody_hip_tree {
   unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
-  int *d_flag = nullptr, *d_incl = nullptr, *d_nid[2] = {nullptr, nullptr};
+  int *d_flag = nullptr, *d_incl = nullptr;  // (kMaxDepth + 1) * max_particles each, level-major
   TreeArrays t{};
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
   unsigned long long* d_visits = nullptr;
+  double* d_partial = nullptr;  // replicas x 3 x n fp64 partial sums (split traversal)
+  int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
   size_t built_count = 0;
 };
 
 static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
-                  g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl, g->d_nid[0], g->d_nid[1],
+                  g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m,
-                  g->d_tmp, g->d_visits};
+                  g->d_tmp, g->d_visits, g->d_partial};
   for (void* p : ptrs) (void)hipFree(p);
   delete g;
 }
@@ -395,17 +511,17 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   if (e == hipSuccess) e = dmalloc(&g->d_idx_a, n);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_b, n);
   if (e == hipSuccess) e = dmalloc(&g->d_sorted, n);
-  if (e == hipSuccess) e = dmalloc(&g->d_flag, n);
-  if (e == hipSuccess) e = dmalloc(&g->d_incl, n);
-  if (e == hipSuccess) e = dmalloc(&g->d_nid[0], n);
-  if (e == hipSuccess) e = dmalloc(&g->d_nid[1], n);
+  const size_t nflag = (size_t)(kMaxDepth + 1) * n;
+  if (e == hipSuccess) e = dmalloc(&g->d_flag, nflag);
+  if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
   if (e == hipSuccess) e = dmalloc(&g->d_visits, 1);
+  if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
   if (e == hipSuccess) {
     size_t t1 = 0, t2 = 0;
     e = rocprim::radix_sort_pairs(nullptr, t1, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n, 0,
                                   30, ctx->stream);
     if (e == hipSuccess)
-      e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, n, rocprim::plus<int>(), ctx->stream);
+      e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, nflag, rocprim::plus<int>(), ctx->stream);
     g->tmp_bytes = t1 > t2 ? t1 : t2;
     if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
   }
@@ -473,25 +589,26 @@ extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data
                                     0, 30, st));
   hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
   NBH_LAUNCH_CHECK();
-  NBH_HIP(hipMemsetAsync(g->t.child0, 0xff, (size_t)g->capacity * sizeof(int), st));  // -1 = leaf
-
-  for (int L = 0; L <= g->max_depth; L++) {
-    int* prev = g->d_nid[(L + 1) & 1];
-    int* cur = g->d_nid[L & 1];
-    // at the last level no node may open children: every node there is a leaf.  Levels beyond
-    // max_depth are not built, so a parent at max_depth keeps child0 = -1.
-    hipLaunchKernelGGL(level_flag_kernel, dim3(blocks), dim3(kBlock), 0, st, g->d_keys_b, ni, L,
-                       g->leaf_max, prev, g->t, g->d_flag);
-    tmp = g->tmp_bytes;
-    NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, g->d_flag, g->d_incl, n, rocprim::plus<int>(), st));
-    hipLaunchKernelGGL(level_fill_kernel, dim3(blocks), dim3(kBlock), 0, st, g->d_keys_b, ni, L,
-                       g->leaf_max, prev, g->d_incl, g->t, g->capacity, cur, g->d_level_base);
-    NBH_LAUNCH_CHECK();
-  }
-  for (int L = g->max_depth; L >= 0; L--) {
-    hipLaunchKernelGGL(level_monopole_kernel, dim3(L < 3 ? 2 : 1024), dim3(kBlock), 0, st, L,
-                       g->d_level_base, g->d_sorted, g->d_root, g->t);
-  }
+  // topology of every level: flags, one scan, fill (see tree_flags_kernel)
+  const int levels = g->max_depth + 1;
+  const size_t total = (size_t)levels * n;
+  hipLaunchKernelGGL(tree_flags_kernel, dim3(blocks), dim3(kBlock), 0, st, g->d_keys_b, ni, g->max_depth,
+                     g->leaf_max, g->d_flag);
+  NBH_LAUNCH_CHECK();
+  tmp = g->tmp_bytes;
+  NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, g->d_flag, g->d_incl, total, rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(tree_fill_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                     g->d_keys_b, ni, g->max_depth, g->leaf_max, g->d_flag, g->d_incl, g->t, g->capacity,
+                     g->d_level_base);
+  NBH_LAUNCH_CHECK();
+  // monopoles bottom-up: wide levels one launch each, the narrow top (all levels when the whole
+  // tree is small) in a single workgroup
+  const int top = n <= 16384 ? g->max_depth : (g->max_depth < 4 ? g->max_depth : 4);
+  for (int L = g->max_depth; L > top; L--)
+    hipLaunchKernelGGL(level_monopole_kernel, dim3(1024), dim3(kBlock), 0, st, L, g->d_level_base,
+                       g->d_sorted, g->d_root, g->t);
+  hipLaunchKernelGGL(top_monopole_kernel, dim3(1), dim3(kTopBlock), 0, st, top, g->d_level_base, g->d_sorted,
+                     g->d_root, g->t);
   NBH_LAUNCH_CHECK();
   g->built_count = n;
   return NBODY_HIP_OK;
@@ -512,15 +629,41 @@ extern "C" int nbody_hip_tree_compute_forces(nbody_hip_tree* g, nbody_particle_d
   const int blocks = (n + kBlock - 1) / kBlock;
   const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
   NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), ctx->stream));
-  if (eps2 < 1e-12f)
-    hipLaunchKernelGGL(bh_traverse_kernel<true>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.rec,
-                       g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y, d->acc_z,
-                       g->d_visits);
-  else
-    hipLaunchKernelGGL(bh_traverse_kernel<false>, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->t.rec,
-                       g->d_sorted, g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y, d->acc_z,
-                       g->d_visits);
+  // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
+  int K = 1;
+  while (K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitBudget) K *= 2;
+  if (g->tune_replicas > 0) {
+    K = 1;
+    while (K < g->tune_replicas && K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitBudget) K *= 2;
+  }
+  if (K < 4 && g->tune_replicas <= 0) K = 1;  // measured: two replicas do not pay for the shared zone
+  int split_level = g->tune_split_level > 0 ? g->tune_split_level : 3;
+  if (split_level > g->max_depth - 1) split_level = g->max_depth - 1;
+  if (split_level < 1) K = 1;
+  const bool guard = eps2 < 1e-12f;
+#define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
+  hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
+                     g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y, d->acc_z, g->d_visits,          \
+                     g->d_level_base, split_level, g->d_partial)
+  if (K == 1) {
+    if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
+  } else {
+    if (guard) NBH_BH_LAUNCH(true, true, dim3(blocks, K)); else NBH_BH_LAUNCH(false, true, dim3(blocks, K));
+    hipLaunchKernelGGL(bh_combine_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->d_partial, K,
+                       g->d_idx_b, n, G, d->acc_x, d->acc_y, d->acc_z);
+  }
+#undef NBH_BH_LAUNCH
   NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+// experiments: replicas / split level of the split traversal (0 = automatic)
+extern "C" int nbody_hip_tree_tuning(nbody_hip_tree* g, int replicas, int split_level) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (replicas < 0 || replicas > kMaxReplicas || split_level < 0 || split_level > kMaxDepth - 1)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "replicas must be in [0, %d], split_level in [0, %d]", kMaxReplicas, kMaxDepth - 1);
+  g->tune_replicas = replicas;
+  g->tune_split_level = split_level;
   return NBODY_HIP_OK;
 }
 
@@ -530,6 +673,7 @@ extern "C" int nbody_hip_tree_stats(nbody_hip_tree* g, int* node_count, float* r
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
   if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree has not been built");
   nbody_hip_ctx* ctx = g->ctx;
+  NBH_NOT_CAPTURABLE(ctx, "tree inspection");
   NBH_HIP(hipSetDevice(ctx->device));
   NBH_HIP(hipStreamSynchronize(ctx->stream));
   int lb[kMaxDepth + 3];
@@ -554,6 +698,7 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
   if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree has not been built");
   nbody_hip_ctx* ctx = g->ctx;
+  NBH_NOT_CAPTURABLE(ctx, "tree inspection");
   NBH_HIP(hipSetDevice(ctx->device));
   NBH_HIP(hipStreamSynchronize(ctx->stream));
   int lb[kMaxDepth + 3];

@@ -22,6 +22,15 @@ int fail(nbody_hip_status code, const char* file, int line, const char* fmt, ...
 
 #define NBH_FAIL(code, ...) ::nbh::fail((code), __FILE__, __LINE__, __VA_ARGS__)
 
+// calls that hand data back to the host cannot be recorded into a step graph
+#define NBH_NOT_CAPTURABLE(ctx, what)                                                          \
+  do {                                                                                        \
+    if ((ctx)->capturing) {                                                                   \
+      (ctx)->capture_failed = true;                                                           \
+      return NBH_FAIL(NBODY_HIP_ERR_STATE, "%s cannot be recorded into a step graph", what);   \
+    }                                                                                         \
+  } while (0)
+
 // HIP call that turns an error into NBODY_HIP_ERR_DEVICE (or _RESOURCE for OOM),
 // message "<call>: <hip error string> at file:line" (ref: CUDA_CHECK, error_handling.hpp:104-114)
 #define NBH_HIP(call)                                                                         \
@@ -54,6 +63,10 @@ struct nbody_hip_ctx {
   nbh::Workspace reduce;             // block partials for energy reductions
   double* host_scalar = nullptr;     // pinned, 4 doubles
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t capture_stream = nullptr;  // library-owned, only used while recording a step graph
+  hipStream_t user_stream = nullptr;     // ctx->stream saved by capture_begin
+  bool capturing = false;
+  mutable bool capture_failed = false;           // a non-capturable call was made while recording
   // tuning overrides (variant -1 / others 0 = automatic)
   int tune_variant = -1, tune_tpl = 0, tune_splits = 0;
 };

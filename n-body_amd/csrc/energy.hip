@@ -109,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restr
 using namespace nbh;
 
 static int energy_check(const nbody_hip_ctx* ctx, const nbody_particle_data* d, const void* out) {
+  if (ctx) NBH_NOT_CAPTURABLE(ctx, "an energy reduction");
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
   if (!d || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (d->count > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");

@@ -395,6 +395,8 @@ static int bits_for(long long total) {
 // the GLOBAL box so that every rank bins on the same grid.
 static int grid_build_packed(nbody_hip_grid* g, const float4* posm, size_t n, const float* bounds) {
   nbody_hip_ctx* ctx = g->ctx;
+  // the grid dimensions come back to the host every build (they size the force launch)
+  NBH_NOT_CAPTURABLE(ctx, "the spatial-hash grid build");
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;

@@ -241,3 +241,43 @@ def test_full_size_two_galaxies(nb, oracle, ctx):
     assert rel_err(acc_of(d)[idx], ref).max() < TOL
     calc.computeForces(d)
     assert np.array_equal(acc_of(d), a)  # reproducible
+
+
+# the split walk (few bodies: K replicas share each wave's walk) against the plain walk: same
+# interactions, different summation grouping -> equal to fp rounding; every setting reproducible
+@pytest.mark.parametrize("n,eps,max_depth", [(6000, 0.02, 10), (6000, 0.0, 10), (700, 0.05, 10), (5000, 0.02, 3),
+                                             (5000, 0.02, 2), (64, 0.05, 10)])
+def test_split_walk_equals_plain_walk(nb, ctx, n, eps, max_depth):
+    ic = nb.ic.plummer(n, seed=21)
+    d, _ = to_device(nb, ic)
+    tree = nb.BarnesHutTree(n)
+    tree.setParams(max_depth, 1)
+    tree.build(d)
+    tree.tuning(1, 0)
+    tree.computeForces(d, 0.6, 1.0, eps)
+    plain = acc_of(d)
+    assert np.isfinite(plain).all()
+    for replicas, level in ((2, 1), (4, 2), (16, 3), (16, 5), (8, 9), (0, 0)):
+        tree.tuning(replicas, level)
+        tree.computeForces(d, 0.6, 1.0, eps)
+        a = acc_of(d)
+        assert rel_err(a, plain).max() < 2e-6, (replicas, level)
+        tree.computeForces(d, 0.6, 1.0, eps)
+        assert np.array_equal(acc_of(d), a), (replicas, level)
+    with pytest.raises(nb.ValidationException):
+        tree.tuning(17, 0)
+
+
+# sizes on both sides of the automatic switch between the split and the plain walk
+@pytest.mark.parametrize("n", [16384, 50000, 70000])
+def test_forces_match_oracle_tree_mid_sizes(nb, oracle, ctx, n):
+    ic = nb.ic.two_galaxies(n, seed=8)
+    d, _ = to_device(nb, ic)
+    calc = nb.BarnesHutCalculator(0.5)
+    calc.setSofteningParameter(0.02)
+    calc.computeForces(d)
+    a = acc_of(d)
+    r = oracle.barnes_hut_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], np.arange(n), 1.0,
+                                 float(np.float32(0.02) ** 2), 0.5)
+    assert rel_err(a, np.stack(r[:3], 1)).max() < TOL
+    assert calc.getTree().stats()["node_count"] == r[4]

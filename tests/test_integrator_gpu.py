@@ -178,3 +178,50 @@ def test_energies_match_oracle(nb, oracle, ctx):
     assert abs(ke - oracle.kinetic_energy(s, 256, 2)) / ke < 1e-6
     ref = oracle.potential_energy(s, 1.5, 0.01, 256, 2)
     assert abs(pe - ref) / abs(ref) < 1e-6
+
+
+# ---- step graphs (include/nbody_hip.h "step graphs"): a recorded step replays to the same bits ----
+
+@pytest.mark.parametrize("method,n", [("bh", 3000), ("bh", 40000), ("direct", 2000), ("direct", 40000)])
+def test_step_graph_replays_eager_steps(nb, ctx, method, n):
+    ic = nb.ic.plummer(n, seed=31)
+    out = []
+    for graph in (False, True):
+        d, _ = to_device(nb, ic)
+        fc = nb.BarnesHutCalculator(0.5) if method == "bh" else nb.DirectForceCalculator()
+        fc.setSofteningParameter(0.05)
+        integ = nb.Integrator()
+        fc.computeForces(d)
+        integ.integrate_steps(d, fc, 1e-3, 4, graph=graph)
+        integ.integrate_steps(d, fc, 1e-3, 3, graph=graph)   # second call reuses the recording
+        out.append(np.stack([d.pos_x.cpu().numpy(), d.vel_y.cpu().numpy(), d.acc_z.cpu().numpy()]))
+        if graph:
+            fc.setSofteningParameter(0.06)                    # parameters are baked in: re-recorded
+            integ.integrate_steps(d, fc, 1e-3, 2, graph=True)
+            assert np.isfinite(d.pos_x.cpu().numpy()).all()
+    assert np.array_equal(out[0], out[1])
+
+
+def test_step_graph_rejects_host_round_trips(nb, ctx):
+    ic = nb.ic.uniform_box(2000, seed=3, lo=-4.0, hi=4.0)
+    d, _ = to_device(nb, ic)
+    integ = nb.Integrator()
+    sh = nb.SpatialHashCalculator(1.0, 1.0)
+    sh.computeForces(d)
+    with pytest.raises(nb.NBodyError):
+        with ctx.capture():
+            sh.computeForces(d)            # the grid size comes back to the host every build
+    with pytest.raises(nb.NBodyError):
+        with ctx.capture():
+            integ.computeKineticEnergy(d)  # returns a value to the host
+    # the context is usable again, eagerly and for a new recording
+    ke = integ.computeKineticEnergy(d)
+    assert np.isfinite(ke)
+    with ctx.capture() as rec:
+        integ.updatePositions(d, 1e-3)
+    x0 = d.pos_x.cpu().numpy().copy()
+    rec.graph.launch(2)
+    ctx.synchronize()
+    assert not np.array_equal(d.pos_x.cpu().numpy(), x0) or np.all(d.vel_x.cpu().numpy() == 0)
+    # integrate_steps(graph=True) with a spatial-hash calculator silently stays eager
+    integ.integrate_steps(d, sh, 1e-3, 2, graph=True)
