@@ -194,6 +194,17 @@ NBODY_HIP_API int nbody_hip_kinetic_energy_f64(nbody_hip_ctx* ctx, const nbody_p
 NBODY_HIP_API int nbody_hip_potential_energy_f64(nbody_hip_ctx* ctx, const nbody_particle_data* d, float G,
                                    float eps, double* out);
 
+/* e (SURVEY 8e "KE/PE via all-reduce of one fp64"): energies of ONE SHARD of a sharded run.
+ * out[0] = sum over the targets of 0.5 m v^2; out[1] = -G/2 sum_{i in targets} m_i sum_{j in sources,
+ * j != self_offset + i} m_j / sqrt(r_ij^2 + eps^2): target i is source number self_offset + i (for
+ * disjoint sets pass self_offset >= n_sources or <= -n_targets, so that no target maps to a source).  Summed over a partition of the
+ * bodies (each rank: its shard against the gathered bodies) the two numbers are the system's KE
+ * and PE as nbody_hip_*_energy_f64 computes them.  Same per-term fp32 arithmetic, fp64 sums. */
+NBODY_HIP_API int nbody_hip_energies_packed(nbody_hip_ctx* ctx, const nbody_float4* targets_posm,
+                                            const nbody_float4* targets_vel, size_t n_targets,
+                                            long long self_offset, const nbody_float4* sources_posm,
+                                            size_t n_sources, float G, float eps, double out[2]);
+
 /* ---- a9: spatial hash (ref: SpatialHashGrid / SpatialHashCalculator,
  *          src/cuda/force_spatial_hash.cu:14-377, include/nbody/spatial_hash_grid.hpp:9-59) ---- */
 

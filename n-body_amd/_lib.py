@@ -85,6 +85,8 @@ PROTOTYPES = {
     "nbody_hip_kinetic_energy_f64": (C.c_int, [_P, _PD, C.POINTER(C.c_double)]),
     "nbody_hip_potential_energy_f64": (C.c_int, [_P, _PD, C.c_float, C.c_float,
                                                  C.POINTER(C.c_double)]),
+    "nbody_hip_energies_packed": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_longlong, _P, C.c_size_t, C.c_float, C.c_float,
+                                            C.POINTER(C.c_double)]),
     "nbody_hip_grid_create": (C.c_int, [_P, C.c_size_t, C.c_float, C.POINTER(_P)]),
     "nbody_hip_grid_destroy": (C.c_int, [_P]),
     "nbody_hip_grid_set_cell_size": (C.c_int, [_P, C.c_float]),

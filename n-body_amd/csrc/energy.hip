@@ -62,15 +62,21 @@ __global__ __launch_bounds__(kBlock) void final_sum_kernel(const double* __restr
 
 // PE: block = 256 targets; grid.y splits the source range.  partial[by * gridDim.x + bx] =
 // sum_i m_i * sum_{j in split, j != i} m_j / sqrt(r_ij^2 + eps^2)
-__global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restrict__ posm, int n,
+// Targets and sources may be different arrays (one shard against the gathered bodies): target i
+// is source number self_offset + i (no such source when the sets are disjoint).
+__global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restrict__ tgt, int nt,
+                                                           long long self_offset,
+                                                           const float4* __restrict__ posm, int n,
                                                            int src_per_split, float eps2,
                                                            double* __restrict__ partial) {
   __shared__ float4 tile[2][PTS];
   __shared__ double red[4];
   const int tid = threadIdx.x;
-  const int i = blockIdx.x * kBlock + tid;
+  const int ti = blockIdx.x * kBlock + tid;
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n) pi = posm[i];
+  if (ti < nt) pi = tgt[ti];
+  const long long self = self_offset + ti;
+  const int i = (self >= 0 && self < n) ? (int)self : -1;
   const int j0 = blockIdx.y * src_per_split;
   const int j1 = min(n, j0 + src_per_split);
   const int ntiles = (j1 - j0 + PTS - 1) / PTS;
@@ -102,6 +108,21 @@ __global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restr
   total *= (double)pi.w;
   const double s = block_sum(total, red);
   if (tid == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void kinetic_packed_kernel(const float4* __restrict__ posm,
+                                                                const float4* __restrict__ vel, size_t n,
+                                                                double* __restrict__ partial) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const float4 v = vel[i];
+    const float v2 = v.x * v.x + v.y * v.y + v.z * v.z;  // integrator.cu:61
+    acc += (double)(0.5f * posm[i].w * v2);              // :62
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 }  // namespace nbh
@@ -163,8 +184,8 @@ extern "C" int nbody_hip_potential_energy_f64(nbody_hip_ctx* ctx, const nbody_pa
   const size_t np = (size_t)bx * splits;
   if (int rc = ctx->reduce.reserve((np + 1) * sizeof(double))) return rc;
   double* partial = static_cast<double*>(ctx->reduce.ptr);
-  hipLaunchKernelGGL(potential_kernel, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, posm, (int)n,
-                     tiles_per_split * PTS, eps * eps, partial);
+  hipLaunchKernelGGL(potential_kernel, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, posm, (int)n, 0LL,
+                     posm, (int)n, tiles_per_split * PTS, eps * eps, partial);
   NBH_LAUNCH_CHECK();
   // ordered pairs counted twice -> * 0.5; sign and G here (integrator.cu:102: pe -= G mi mj / r)
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial, (int)np,
@@ -192,5 +213,55 @@ extern "C" int nbody_hip_potential_energy(nbody_hip_ctx* ctx, const nbody_partic
   if (!out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (int rc = nbody_hip_potential_energy_f64(ctx, d, G, eps, &v)) return rc;
   *out = (float)v;
+  return NBODY_HIP_OK;
+}
+
+// e: energies of one shard of a sharded run (the sum over the shards is the system's KE and PE)
+extern "C" int nbody_hip_energies_packed(nbody_hip_ctx* ctx, const nbody_float4* targets_posm,
+                                         const nbody_float4* targets_vel, size_t n_targets,
+                                         long long self_offset, const nbody_float4* sources_posm,
+                                         size_t n_sources, float G, float eps, double out[2]) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  NBH_NOT_CAPTURABLE(ctx, "an energy reduction");
+  if (!out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  out[0] = out[1] = 0.0;
+  if (n_targets == 0) return NBODY_HIP_OK;
+  if (!targets_posm || !targets_vel || (n_sources > 0 && !sources_posm))
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (n_targets > 0x3fffffffu || n_sources > 0x3fffffffu)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");
+  NBH_HIP(hipSetDevice(ctx->device));
+  const float4* tp = reinterpret_cast<const float4*>(targets_posm);
+  const float4* tv = reinterpret_cast<const float4*>(targets_vel);
+  const float4* sp = reinterpret_cast<const float4*>(sources_posm);
+  const int bx = (int)((n_targets + kBlock - 1) / kBlock);
+  const int kb = bx > 1024 ? 1024 : bx;
+  const int tiles = (int)((n_sources + PTS - 1) / PTS);
+  int splits = (kNumCU * 8 + bx - 1) / bx;
+  if (splits > 64) splits = 64;
+  if (splits > tiles) splits = tiles;
+  if (splits < 1) splits = 1;
+  const int tiles_per_split = tiles > 0 ? (tiles + splits - 1) / splits : 1;
+  splits = tiles > 0 ? (tiles + tiles_per_split - 1) / tiles_per_split : 0;
+  const size_t np = (size_t)bx * splits;
+  if (int rc = ctx->reduce.reserve((np + (size_t)kb + 2) * sizeof(double))) return rc;
+  double* partial = static_cast<double*>(ctx->reduce.ptr);
+  double* kpart = partial + np;
+  double* res = kpart + kb;  // {ke, pe}
+  hipLaunchKernelGGL(kinetic_packed_kernel, dim3(kb), dim3(kBlock), 0, ctx->stream, tp, tv, n_targets, kpart);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, kpart, kb, 1.0, res);
+  if (np > 0) {
+    hipLaunchKernelGGL(potential_kernel, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, tp, (int)n_targets,
+                       self_offset, sp, (int)n_sources, tiles_per_split * PTS, eps * eps, partial);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial, (int)np,
+                       -0.5 * (double)G, res + 1);
+  } else {
+    NBH_HIP(hipMemsetAsync(res + 1, 0, sizeof(double), ctx->stream));
+  }
+  NBH_LAUNCH_CHECK();
+  NBH_HIP(hipMemcpyAsync(ctx->host_scalar, res, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NBH_HIP(hipStreamSynchronize(ctx->stream));
+  out[0] = ctx->host_scalar[0];
+  out[1] = ctx->host_scalar[1];
   return NBODY_HIP_OK;
 }

@@ -57,6 +57,14 @@ class HipBackend:
     def forces_pair(self, a, b, G, eps2, acc_a, acc_b, accumulate_a, accumulate_b):
         direct_forces_pair_packed(self.ctx, a, b, G, eps2, acc_a, acc_b, accumulate_a, accumulate_b)
 
+    def energies(self, posm, vel, self_offset, sources, G, eps):
+        """(KE of the shard, its share of the PE): nbody_hip_energies_packed."""
+        out = (C.c_double * 2)()
+        check(self.ctx._lib.nbody_hip_energies_packed(self.ctx.handle, posm.data_ptr(), vel.data_ptr(),
+                                                      posm.shape[0], self_offset, sources.data_ptr(),
+                                                      sources.shape[0], G, eps, out))
+        return float(out[0]), float(out[1])
+
     # -- spatial hash (z-slab path) ------------------------------------------------------------
     def bbox(self, posm):
         """{lo x,y,z, hi x,y,z} of packed bodies as a device tensor of 6 floats."""
@@ -220,14 +228,24 @@ class ShardedDirectSystem:
         dist.all_gather_into_tensor(full, t.contiguous(), group=self.group)
         return full[: self.n].cpu().numpy()
 
-    def kinetic_energy(self) -> float:
-        """0.5 sum m v^2 over all ranks: local fp64 sum + all-reduce of one double."""
-        m = self.posm[:, 3].double()
-        v2 = (self.vel[:, :3].double() ** 2).sum(1)
-        ke = (0.5 * m * v2).sum().reshape(1)
+    def energies(self, eps: float | None = None):
+        """(KE, PE) of the whole system on every rank: each rank reduces its shard
+        against the gathered bodies on the device, then ONE all-reduce of two doubles."""
+        eps = float(np.sqrt(self.eps2)) if eps is None else float(eps)
+        src = self.posm
         if self.world > 1:
-            dist.all_reduce(ke, group=self.group)
-        return float(ke.item())
+            dist.all_gather_into_tensor(self.posm_all, self.posm, group=self.group)
+            src = self.posm_all
+        ke, pe = self.backend.energies(self.posm, self.vel, self.rank * self.S, src, self.G, eps)
+        e = torch.tensor([ke, pe], dtype=torch.float64)
+        if self.world > 1:
+            if dist.get_backend(self.group) != "gloo":
+                e = e.to(self.device)
+            dist.all_reduce(e, group=self.group)
+        return float(e[0]), float(e[1])
+
+    def kinetic_energy(self) -> float:
+        return self.energies()[0]
 
 
 def layer_owner(gz: int, world: int) -> np.ndarray:

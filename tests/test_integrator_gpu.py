@@ -225,3 +225,33 @@ def test_step_graph_rejects_host_round_trips(nb, ctx):
     assert not np.array_equal(d.pos_x.cpu().numpy(), x0) or np.all(d.vel_x.cpu().numpy() == 0)
     # integrate_steps(graph=True) with a spatial-hash calculator silently stays eager
     integ.integrate_steps(d, sh, 1e-3, 2, graph=True)
+
+
+# 8e: per-shard energies (nbody_hip_energies_packed) add up to the whole-system reductions
+@pytest.mark.parametrize("n,parts", [(5000, 3), (777, 4), (40000, 8)])
+def test_shard_energies_sum_to_whole(nb, oracle, ctx, n, parts):
+    from gpu_util import packed
+    from nbody_amd.distributed import HipBackend
+    ic = nb.ic.plummer(n, seed=17)
+    d, _ = to_device(nb, ic)
+    integ = nb.Integrator()
+    ke_ref, pe_ref = integ.computeEnergiesF64(d, 1.3, 0.02)
+    posm = packed(ic)
+    vel = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    for k, f in enumerate(("vel_x", "vel_y", "vel_z")):
+        vel[:, k] = torch.from_numpy(ic[f]).cuda()
+    b = HipBackend(ctx)
+    cuts = np.linspace(0, n, parts + 1).astype(int)
+    ke = pe = 0.0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        k, p = b.energies(posm[lo:hi], vel[lo:hi], int(lo), posm, 1.3, 0.02)
+        ke, pe = ke + k, pe + p
+    assert abs(ke - ke_ref) <= 1e-12 * abs(ke_ref)
+    assert abs(pe - pe_ref) <= 1e-9 * abs(pe_ref)      # same fp32 terms, fp64 sums in another grouping
+    # disjoint sets: no self pair anywhere; the two directions agree
+    a, c = posm[: n // 2], posm[n // 2:]
+    _, pac = b.energies(a, vel[: n // 2], -n, c, 1.0, 0.02)
+    _, pca = b.energies(c, vel[n // 2:], 1 << 40, a, 1.0, 0.02)
+    assert abs(pac - pca) <= 1e-6 * abs(pac)   # fp32 per-pair terms round differently by direction
+    s = host_state(ic)
+    assert abs(pe_ref - oracle.potential_energy(s, 1.3, 0.02, 256, 2)) < 1e-5 * abs(pe_ref)

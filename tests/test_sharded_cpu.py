@@ -53,6 +53,18 @@ class OracleBackend:
         self.forces(a, b, G, eps2, acc_a, accumulate_a)
         self.forces(b, a, G, eps2, acc_b, accumulate_b)
 
+    def energies(self, posm, vel, self_offset, sources, G, eps):
+        # the shard's KE and its share of the PE from the oracle's one-sided sums (fp64 accumulation)
+        p, v, s = posm.numpy().astype(np.float64), vel.numpy().astype(np.float64), sources.numpy().astype(np.float64)
+        ke = float((0.5 * p[:, 3] * (v[:, :3] ** 2).sum(1)).sum())
+        d = s[None, :, :3] - p[:, None, :3]
+        r2 = (d ** 2).sum(2) + float(np.float32(eps) * np.float32(eps))
+        w = s[None, :, 3] / np.sqrt(r2)
+        idx = np.arange(p.shape[0]) + self_offset
+        ok = (idx >= 0) & (idx < s.shape[0])
+        w[np.arange(p.shape[0])[ok], idx[ok]] = 0.0
+        return ke, float(-0.5 * G * (p[:, 3] * w.sum(1)).sum())
+
     # -- spatial hash (z-slab path) -------------------------------------------------------------
     def bbox(self, posm):
         p = posm.numpy()
@@ -102,9 +114,9 @@ def _worker(rank, world, port, n, steps, out_dir, mode=None):
         pos = sysm.gather_global("posm")
         vel = sysm.gather_global("vel")
         acc = sysm.gather_global("acc")
-        ke = sysm.kinetic_energy()
+        ke, pe = sysm.energies()
         if rank == 0:
-            np.savez(os.path.join(out_dir, f"w{world}.npz"), pos=pos, vel=vel, acc=acc, ke=ke)
+            np.savez(os.path.join(out_dir, f"w{world}.npz"), pos=pos, vel=vel, acc=acc, ke=ke, pe=pe)
     finally:
         dist.destroy_process_group()
 
@@ -130,6 +142,8 @@ def test_sharded_steps_match_single_process(tmp_path, world, n, mode, oracle, nb
     for k, col in (("acc_x", 0), ("acc_y", 1), ("acc_z", 2)):
         assert np.allclose(got["acc"][:, col], s[k], rtol=2e-5, atol=1e-6), k
     assert abs(float(got["ke"]) - oracle.kinetic_energy(s, 256, 2)) < 1e-6
+    pe = oracle.potential_energy(s, 1.0, 0.01, 256, 2)
+    assert abs(float(got["pe"]) - pe) < 1e-6 * abs(pe)
 
 
 def test_shard_bounds(nb):

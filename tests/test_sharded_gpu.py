@@ -45,9 +45,9 @@ def _direct_worker(rank, world, port, n, steps, mode, out_dir):
         for _ in range(steps):
             sysm.step(1e-3)
         pos, vel, acc = (sysm.gather_global(k) for k in ("posm", "vel", "acc"))
-        ke = sysm.kinetic_energy()
+        ke, pe = sysm.energies()
         if rank == 0:
-            np.savez(os.path.join(out_dir, "d.npz"), pos=pos, vel=vel, acc=acc, ke=ke)
+            np.savez(os.path.join(out_dir, "d.npz"), pos=pos, vel=vel, acc=acc, ke=ke, pe=pe)
     finally:
         dist.destroy_process_group()
 
@@ -72,6 +72,10 @@ def test_sharded_direct_on_gpu(tmp_path, world, n, mode, oracle, nb):
     assert np.array_equal(got["pos"][:, 3], s["mass"])
     for col, k in enumerate(("vel_x", "vel_y", "vel_z")):
         assert np.allclose(got["vel"][:, col], s[k], rtol=1e-5, atol=1e-6), k
+    # energies: per-shard device reductions + one all-reduce == the single-process fp64 oracle
+    ke, pe = oracle.kinetic_energy(s, 256, 2), oracle.potential_energy(s, 1.0, 0.01, 256, 2)
+    assert abs(float(got["ke"]) - ke) < 1e-5 * abs(ke)
+    assert abs(float(got["pe"]) - pe) < 1e-5 * abs(pe)
 
 
 def _hash_worker(rank, world, port, n, steps, cutoff, out_dir):
