@@ -190,10 +190,60 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
         elapsed = float(t.item())
     if rank != 0:
         return None
-    return {"metric": "steps_per_s", "value": a.steps / elapsed, "unit": "steps/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": name, "bodies": n, "dt": dt, "path": path}}
+    out = {"metric": "steps_per_s", "value": a.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic", "config": {"workload": name, "bodies": n, "dt": dt, "path": path}}
+    if not sharded:
+        out["roofline"] = other_roofline(a, nb, ps, torch)
+    return out
+
+
+def other_roofline(a, nb, ps, torch):
+    """SURVEY 8d figures for the force kernel of configs 4 / 5, timed alone with events on the
+    stream it runs on (the null stream = torch's current stream)."""
+    fc, d = ps.force_calculator_, ps.d_particles_
+    iters = max(1, a.kernel_iters)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.workload == "bh":
+        tree = fc.getTree()
+        run = lambda: tree.computeForces(d, fc.theta_, fc.G_, fc.softening_eps_)  # noqa: E731
+    else:
+        grid = fc.getGrid()
+        run = lambda: grid.computeForces(d, fc.cutoff_radius_, fc.G_, fc.softening_eps_)  # noqa: E731
+    run()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    if a.workload == "bh":
+        st = tree.stats()  # node records fetched by the last walk, summed over waves
+        visits = int(st["nodes_visited"])
+        nbytes = 32.0 * visits + 16.0 * d.count  # 32-byte record per visit + the body itself
+        return {"kernel": "bh_traverse_kernel", "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0,
+                "unit": "GB/s", "frac": nbytes / t / 8e12, "traffic": None, "avg_kernel_ms": t * 1e3,
+                "node_visits_per_s": visits / t, "nodes": st["node_count"],
+                "note": "32 B per node record a wave fetches (scalar cache / L2, mostly not HBM) + 16 B per body; "
+                        "the walk is latency- and issue-bound, see DESIGN.md 4.5"}
+    cs, ce, _, _ = grid.copyCellDataToHost()
+    gx, gy, gz = grid.getGridDims()
+    cnt = (ce - cs).astype(np.int64).reshape(gz, gy, gx)
+    pad = np.pad(cnt, 1)
+    nb27 = np.zeros_like(cnt)
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                nb27 += pad[dz:dz + gz, dy:dy + gy, dx:dx + gx]
+    pairs = float((cnt * nb27).sum())  # candidate pairs: every body against the bodies of its 27 cells
+    flops = 20.0 * pairs
+    return {"kernel": "hash_force_kernel", "bound": "valu", "achieved": flops / t / 1e12, "peak": 157.3,
+            "unit": "TFLOP/s", "frac": flops / t / 157.3e12, "traffic": None, "avg_kernel_ms": t * 1e3,
+            "candidate_pairs_per_s": pairs / t, "gather_bytes_per_s": 16.0 * pairs / t,
+            "note": "20 flop per candidate pair (distance + cutoff test + force); 16 B per candidate pair is the "
+                    "SURVEY 8d gather figure, served from LDS tiles (HBM traffic is 28 B per body)"}
 
 
 def main():
