@@ -353,14 +353,17 @@ def main():
         eps2 = float(np.float32(eps) * np.float32(eps))
         if world == 1:
             # the step's force evaluation: all pairs of one body set -> nbh::direct_sym_kernel
-            kname = "nbh::direct_sym_kernel<8,false>"
+            r = a.tpl if a.tpl in (2, 4, 6, 8, 16) else (16 if n >= 786432 else 8 if n >= 98304 else 4)  # direct_sym.hip sym_R
+            kname = (f"nbh::direct_sym_kernel<{r},false,{'true' if float(np.ptp(ic['mass'])) == 0.0 else 'false'}>"
+                     if n >= 32768 and a.variant in (-1, 3) else "nbh::direct_kernel (one-sided)")
             ms = nb.time_direct_packed(ctx, p, p, G, eps2, a.kernel_iters)
             pairs = float(n) * n
             alg_bytes = 16.0 * n + 16.0 * n
         else:
             # the step's dominant launch: own shard x one remote shard, action + reaction
-            kname = "nbh::direct_sym_kernel<R,true> (shard pair)"
             S = (n + world - 1) // world
+            r = a.tpl if a.tpl in (2, 4, 6, 8, 16) else (16 if S >= 49152 else 8 if S >= 16384 else 4)
+            kname = f"nbh::direct_sym_kernel<{r},true,...> (shard pair)"
             A, B = p[:S].contiguous(), p[S:2 * S].contiguous()
             accA, accB = torch.zeros_like(A), torch.zeros_like(B)
             nb.direct_forces_pair_packed(ctx, A, B, G, eps2, accA, accB)

@@ -15,7 +15,7 @@
 // with a reaction accumulator that TRAVELS WITH THE BODY.  In each of 64 steps a lane pairs its R
 // bodies with the J body it currently holds, adds the reaction into the travelling accumulator,
 // and the seven J registers {x, y, z, m, hx, hy, hz} are rotated one lane along the wave
-// (v_mov_b32_dpp wave_ror:1).  After 64 steps everything is back in its home lane.  The four
+// (v_mov_b32_dpp wave_rol:1).  After 64 steps everything is back in its home lane.  The four
 // waves of the block then combine their reactions through LDS (plain stores + barrier) and one
 // wave adds the 64 x 3 sums to the global fp64 accumulator with hardware f64 atomics (lossless
 // across XCDs, measured ~180 G adds/s).  The I-side sums stay in registers for the whole kernel
@@ -140,25 +140,34 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
 #pragma unroll 2
       for (int k = 0; k < 64; k++) {
         const f2 sxj = {jx, jx}, syj = {jy, jy}, szj = {jz, jz}, smj = {jm, jm};
+        // phases over the R/2 packed pairs: the dependent chain of one pair (r2 -> rsq -> g -> sums)
+        // is interleaved with the other pairs' instead of being padded with hazard nops
+        f2 dx[R / 2], dy[R / 2], dz[R / 2], g[R / 2];
+#pragma unroll
+        for (int r = 0; r < R / 2; r++) {
+          dx[r] = sxj - xi[r]; dy[r] = syj - yi[r]; dz[r] = szj - zi[r];
+          g[r] = __builtin_elementwise_fma(dx[r], dx[r], __builtin_elementwise_fma(dy[r], dy[r], __builtin_elementwise_fma(dz[r], dz[r], e2)));
+        }
+#pragma unroll
+        for (int r = 0; r < R / 2; r++) {
+          g[r].x = __builtin_amdgcn_rsqf(g[r].x);
+          g[r].y = __builtin_amdgcn_rsqf(g[r].y);
+        }
+#pragma unroll
+        for (int r = 0; r < R / 2; r++) g[r] = (g[r] * g[r]) * g[r];
         // the travelling reaction sum rides in the low half of the packed accumulator
         f2 hx = {hjx, 0.f}, hy = {hjy, 0.f}, hz = {hjz, 0.f};
 #pragma unroll
         for (int r = 0; r < R / 2; r++) {
-          const f2 dx = sxj - xi[r], dy = syj - yi[r], dz = szj - zi[r];
-          const f2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, e2)));
-          f2 inv;
-          inv.x = __builtin_amdgcn_rsqf(r2.x);
-          inv.y = __builtin_amdgcn_rsqf(r2.y);
-          const f2 g = (inv * inv) * inv;
-          const f2 fj = EQM ? g : g * smj;    // on the I bodies, from J
-          ax[r] = __builtin_elementwise_fma(fj, dx, ax[r]);
-          ay[r] = __builtin_elementwise_fma(fj, dy, ay[r]);
-          az[r] = __builtin_elementwise_fma(fj, dz, az[r]);
+          const f2 fj = EQM ? g[r] : g[r] * smj;    // on the I bodies, from J
+          ax[r] = __builtin_elementwise_fma(fj, dx[r], ax[r]);
+          ay[r] = __builtin_elementwise_fma(fj, dy[r], ay[r]);
+          az[r] = __builtin_elementwise_fma(fj, dz[r], az[r]);
           if (REACT) {
-            const f2 fi = EQM ? g : g * mi[r];  // on the J body, from the I bodies
-            hx = __builtin_elementwise_fma(-fi, dx, hx);  // a_j -= g m_i d  (neg is an operand modifier)
-            hy = __builtin_elementwise_fma(-fi, dy, hy);
-            hz = __builtin_elementwise_fma(-fi, dz, hz);
+            const f2 fi = EQM ? g[r] : g[r] * mi[r];  // on the J body, from the I bodies
+            hx = __builtin_elementwise_fma(-fi, dx[r], hx);  // a_j -= g m_i d  (neg is an operand modifier)
+            hy = __builtin_elementwise_fma(-fi, dy[r], hy);
+            hz = __builtin_elementwise_fma(-fi, dz[r], hz);
           }
         }
         if (REACT) {
@@ -270,16 +279,22 @@ bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n) {
   return ctx->tune_variant < 0 && n >= 32768;
 }
 
-static int sym_R(const nbody_hip_ctx* ctx, size_t n) {
-  if (ctx->tune_tpl == 2 || ctx->tune_tpl == 4 || ctx->tune_tpl == 6 || ctx->tune_tpl == 8) return ctx->tune_tpl;
-  return n >= 262144 ? 8 : 4;  // measured: R = 8 wins from N = 2.6e5, R = 4 from 3.3e4
+// bodies per lane R, measured (tools/sweep_sym_sizes.py, profiles/r01_sym_R_sweep.txt): the larger R,
+// the fewer rotations per pair but the fewer workgroups; the two-set kernel has NBI x splits
+// workgroups whatever R is, so it takes R = 16 much earlier than the half-ring all-pairs kernel
+static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
+  if (ctx->tune_tpl == 2 || ctx->tune_tpl == 4 || ctx->tune_tpl == 6 || ctx->tune_tpl == 8 ||
+      ctx->tune_tpl == 16)
+    return ctx->tune_tpl;
+  if (two_sets) return n >= 49152 ? 16 : (n >= 16384 ? 8 : 4);
+  return n >= 786432 ? 16 : (n >= 98304 ? 8 : 4);
 }
 
 int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
                      float4* acc4, int accumulate, float* ax, float* ay, float* az, float* vx,
                      float* vy, float* vz, const float* aox, const float* aoy, const float* aoz,
                      float half_dt) {
-  const int R = sym_R(ctx, n);
+  const int R = sym_R(ctx, n, false);
   const int S = kBlock * R;
   const int NB = (int)((n + S - 1) / S);
   const int D = NB / 2;
@@ -302,6 +317,7 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
     case 2: launch_sym<2, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
     case 6: launch_sym<6, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
     case 8: launch_sym<8, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
+    case 16: launch_sym<16, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
     default: launch_sym<4, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
   }
   NBH_LAUNCH_CHECK();
@@ -316,7 +332,7 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
 int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const float4* pj, size_t nj,
                           float G, float eps2, float4* acc_i, int accumulate_i, float4* acc_j,
                           int accumulate_j) {
-  const int R = sym_R(ctx, ni < nj ? ni : nj);
+  const int R = sym_R(ctx, ni < nj ? ni : nj, true);
   const int S = kBlock * R;
   const int NBI = (int)((ni + S - 1) / S), NBJ = (int)((nj + S - 1) / S);
   int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * 16 + NBI - 1) / NBI;
@@ -338,6 +354,7 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
     case 2: launch_sym<2, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
     case 6: launch_sym<6, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
     case 8: launch_sym<8, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
+    case 16: launch_sym<16, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
     default: launch_sym<4, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
   }
   NBH_LAUNCH_CHECK();
