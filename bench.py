@@ -159,16 +159,21 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
             path = "ParticleSystem(SPATIAL_HASH)"
         name = f"uniform_box_N{n}_spatial_hash_cell1_cutoff1_velocity_verlet"
     else:
-        if sharded and world > 1:
-            raise SystemExit("Barnes-Hut is single-GPU (replicas only, DESIGN.md section 5)")
         n = a.n
         ic = nb.ic.two_galaxies(n, seed=42)
         ic["mass"] = (ic["mass"] / np.float32(n)).astype(np.float32)
-        ps = nb.ParticleSystem()
-        ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod.BARNES_HUT, dt=dt,
-                                          softening=0.1, barnes_hut_theta=0.5), initial_conditions=ic)
-        step = lambda: ps.update(dt)  # noqa: E731
-        path = "ParticleSystem(BARNES_HUT, theta 0.5)"
+        if sharded:
+            from nbody_amd.distributed import ShardedTreeSystem
+            sysm = ShardedTreeSystem(ic, 1.0, 0.1, 0.5, backend=HipBackend(ctx))
+            sysm.initial_forces()
+            step = lambda: sysm.step(dt)  # noqa: E731
+            path = "replicated tree, walk partitioned over the ranks, all-gather + reduce-scatter per step"
+        else:
+            ps = nb.ParticleSystem()
+            ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod.BARNES_HUT, dt=dt,
+                                              softening=0.1, barnes_hut_theta=0.5), initial_conditions=ic)
+            step = lambda: ps.update(dt)  # noqa: E731
+            path = "ParticleSystem(BARNES_HUT, theta 0.5)"
         name = f"two_galaxies_N{n}_barnes_hut_theta0.5_velocity_verlet"
 
     def barrier():

@@ -276,6 +276,16 @@ NBODY_HIP_API int nbody_hip_tree_build(nbody_hip_tree* tree, const nbody_particl
 /* ref: BarnesHutTree::computeForces(d_particles, theta, G, eps) :488-498 -- OVERWRITES acc_*. */
 NBODY_HIP_API int nbody_hip_tree_compute_forces(nbody_hip_tree* tree, nbody_particle_data* d,
                                                 float theta, float G, float eps);
+
+/* e (multi-GPU Barnes-Hut: replicated tree, partitioned walk; no reference counterpart).
+ * build_packed: the same build from float4 {x, y, z, m} bodies (the gathered bodies of all ranks).
+ * compute_forces_packed: walks only the bodies at positions [first_sorted, first_sorted + count) of
+ * the tree's Morton-sorted order and writes their accelerations as {ax, ay, az, 0} at the bodies'
+ * ORIGINAL indices of acc_out (n float4, rows of other bodies untouched).  Ranks that walk disjoint
+ * ranges of the same tree produce, together, exactly the single-GPU result. */
+NBODY_HIP_API int nbody_hip_tree_build_packed(nbody_hip_tree* tree, const nbody_float4* posm, size_t n);
+NBODY_HIP_API int nbody_hip_tree_compute_forces_packed(nbody_hip_tree* tree, size_t first_sorted, size_t count,
+                                                       float theta, float G, float eps, nbody_float4* acc_out);
 /* ref: getNodeCount (barnes_hut_tree.hpp:41) and the root mass used by verifyMassConservation
  * (:511-519); plus node visits (per wave) of the last traversal and the first node id of every
  * level (12 ints).  Any output may be NULL.  Blocking. */

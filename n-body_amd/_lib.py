@@ -105,6 +105,8 @@ PROTOTYPES = {
     "nbody_hip_tree_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_tree_build": (C.c_int, [_P, _PD]),
     "nbody_hip_tree_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
+    "nbody_hip_tree_build_packed": (C.c_int, [_P, _P, C.c_size_t]),
+    "nbody_hip_tree_compute_forces_packed": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_float, _P]),
     "nbody_hip_tree_stats": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float),
                                        C.POINTER(C.c_ulonglong), C.POINTER(C.c_int * 12)]),
     "nbody_hip_tree_copy_nodes": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -294,18 +294,20 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 template <bool GUARD, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
-    const int* __restrict__ idx, int n, float theta2, float eps2, float G,
-    float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
+    const int* __restrict__ idx, int t_first, int n, float theta2, float eps2, float G,
+    float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4,
     unsigned long long* __restrict__ visit_count, const int* __restrict__ level_base, int split_level,
     double* __restrict__ partial) {
+  // walks the sorted bodies [t_first, t_first + n) (a sharded run gives each rank a range)
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[4][kStack];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int replica = SPLIT ? (int)blockIdx.y : 0;
   const int rmask = SPLIT ? (int)gridDim.y - 1 : 0;  // K is a power of two
   const int split_end = SPLIT ? level_base[split_level + 1] : 0;
-  const int t = blockIdx.x * kBlock + tid;
-  const bool valid = t < n;
+  const int tl = blockIdx.x * kBlock + tid;  // position in the range
+  const int t = t_first + tl;                // position in the sorted body list
+  const bool valid = tl < n;
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid) pi = sorted[t];
   double sx = 0.0, sy = 0.0, sz = 0.0;  // fp32 sums of one sibling group are folded into fp64
@@ -394,22 +396,26 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   if (valid) {
     if (SPLIT) {
       double* p = partial + (size_t)replica * 3 * n;
-      p[t] = sx; p[(size_t)n + t] = sy; p[2 * (size_t)n + t] = sz;
+      p[tl] = sx; p[(size_t)n + tl] = sy; p[2 * (size_t)n + tl] = sz;
     } else {
       const int i = idx[t];
-      acc_x[i] = (float)((double)G * sx);
-      acc_y[i] = (float)((double)G * sy);
-      acc_z[i] = (float)((double)G * sz);
+      const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
+      if (acc4) {
+        acc4[i] = make_float4(fx, fy, fz, 0.f);
+      } else {
+        acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
+      }
     }
   }
   if (visit_count && lane == 0) atomicAdd(visit_count, visited);
 }
 
 __global__ __launch_bounds__(kBlock) void bh_combine_kernel(const double* __restrict__ partial, int replicas,
-                                                            const int* __restrict__ idx, int n, float G,
-                                                            float* __restrict__ acc_x,
+                                                            const int* __restrict__ idx, int t_first, int n,
+                                                            float G, float* __restrict__ acc_x,
                                                             float* __restrict__ acc_y,
-                                                            float* __restrict__ acc_z) {
+                                                            float* __restrict__ acc_z,
+                                                            float4* __restrict__ acc4) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= n) return;
   double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -417,10 +423,13 @@ __global__ __launch_bounds__(kBlock) void bh_combine_kernel(const double* __rest
     const double* p = partial + (size_t)r * 3 * n;
     sx += p[t]; sy += p[(size_t)n + t]; sz += p[2 * (size_t)n + t];
   }
-  const int i = idx[t];
-  acc_x[i] = (float)((double)G * sx);
-  acc_y[i] = (float)((double)G * sy);
-  acc_z[i] = (float)((double)G * sz);
+  const int i = idx[t_first + t];
+  const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
+  if (acc4) {
+    acc4[i] = make_float4(fx, fy, fz, 0.f);
+  } else {
+    acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
+  }
 }
 
 }  // namespace nbh
@@ -560,22 +569,10 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
   return tree_alloc_nodes(g);
 }
 
-extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data* d) {
-  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
-  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
-  const size_t n = d->count;
-  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
-  if (n > g->max_particles)
-    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the tree's capacity %zu "
-                    "(sized from the first count seen, ref: force_barnes_hut.cu:527-529)", n, g->max_particles);
-  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass)
-    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+// the build proper, from packed bodies
+static int tree_build_packed(nbody_hip_tree* g, const float4* posm, size_t n) {
   nbody_hip_ctx* ctx = g->ctx;
-  NBH_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
-  float4* posm = static_cast<float4*>(ctx->posm.ptr);
-  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
 
@@ -614,21 +611,47 @@ extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data
   return NBODY_HIP_OK;
 }
 
-extern "C" int nbody_hip_tree_compute_forces(nbody_hip_tree* g, nbody_particle_data* d, float theta,
-                                             float G, float eps) {
+extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data* d) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
   if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
-  if (g->built_count == 0 || g->built_count != d->count)
-    return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree was not built for this particle set");
-  if (!d->acc_x || !d->acc_y || !d->acc_z) return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  const size_t n = d->count;
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the tree's capacity %zu "
+                    "(sized from the first count seen, ref: force_barnes_hut.cu:527-529)", n, g->max_particles);
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
+  return tree_build_packed(g, posm, n);
+}
+
+extern "C" int nbody_hip_tree_build_packed(nbody_hip_tree* g, const nbody_float4* posm, size_t n) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (!posm) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the tree's capacity %zu", n, g->max_particles);
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  return tree_build_packed(g, reinterpret_cast<const float4*>(posm), n);
+}
+
+// walk of the sorted bodies [first, first + count); output SoA (ax, ay, az) or float4 (acc4), at
+// the bodies' ORIGINAL indices
+static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float G, float eps, float* ax,
+                     float* ay, float* az, float4* acc4) {
   if (!(theta >= 0.0f) || theta > 2.0f)  // ref: validateTheta, error_handling.cpp:115-123
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Barnes-Hut theta must be between 0 and 2");
   nbody_hip_ctx* ctx = g->ctx;
   NBH_HIP(hipSetDevice(ctx->device));
-  const int n = (int)g->built_count;
+  const int n = count;
   const int blocks = (n + kBlock - 1) / kBlock;
   const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
   NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), ctx->stream));
+  if (n == 0) return NBODY_HIP_OK;
   // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
   int K = 1;
   while (K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitBudget) K *= 2;
@@ -643,18 +666,40 @@ extern "C" int nbody_hip_tree_compute_forces(nbody_hip_tree* g, nbody_particle_d
   const bool guard = eps2 < 1e-12f;
 #define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
-                     g->d_idx_b, n, theta2, eps2, G, d->acc_x, d->acc_y, d->acc_z, g->d_visits,          \
+                     g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, g->d_visits,               \
                      g->d_level_base, split_level, g->d_partial)
   if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
   } else {
     if (guard) NBH_BH_LAUNCH(true, true, dim3(blocks, K)); else NBH_BH_LAUNCH(false, true, dim3(blocks, K));
     hipLaunchKernelGGL(bh_combine_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, g->d_partial, K,
-                       g->d_idx_b, n, G, d->acc_x, d->acc_y, d->acc_z);
+                       g->d_idx_b, first, n, G, ax, ay, az, acc4);
   }
 #undef NBH_BH_LAUNCH
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_compute_forces(nbody_hip_tree* g, nbody_particle_data* d, float theta,
+                                             float G, float eps) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  if (g->built_count == 0 || g->built_count != d->count)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree was not built for this particle set");
+  if (!d->acc_x || !d->acc_y || !d->acc_z) return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  return tree_walk(g, 0, (int)g->built_count, theta, G, eps, d->acc_x, d->acc_y, d->acc_z, nullptr);
+}
+
+extern "C" int nbody_hip_tree_compute_forces_packed(nbody_hip_tree* g, size_t first_sorted, size_t count,
+                                                    float theta, float G, float eps, nbody_float4* acc_out) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (!acc_out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree has not been built");
+  if (first_sorted > g->built_count || count > g->built_count - first_sorted)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "range [%zu, %zu) exceeds the %zu bodies of the tree", first_sorted,
+                    first_sorted + count, g->built_count);
+  return tree_walk(g, (int)first_sorted, (int)count, theta, G, eps, nullptr, nullptr, nullptr,
+                   reinterpret_cast<float4*>(acc_out));
 }
 
 // experiments: replicas / split level of the split traversal (0 = automatic)

@@ -281,3 +281,39 @@ def test_forces_match_oracle_tree_mid_sizes(nb, oracle, ctx, n):
                                  float(np.float32(0.02) ** 2), 0.5)
     assert rel_err(a, np.stack(r[:3], 1)).max() < TOL
     assert calc.getTree().stats()["node_count"] == r[4]
+
+
+# 8e: ranks walk disjoint ranges of the same (replicated) tree; together they give the whole walk
+@pytest.mark.parametrize("n,parts", [(300000, 4), (300000, 1), (9000, 3)])
+def test_range_walks_equal_whole_walk(nb, ctx, n, parts):
+    import ctypes as C
+    from gpu_util import packed
+    from nbody_amd._lib import check
+    ic = nb.ic.two_galaxies(n, seed=4)
+    d, _ = to_device(nb, ic)
+    calc = nb.BarnesHutCalculator(0.5)
+    calc.setSofteningParameter(0.05)
+    calc.computeForces(d)
+    whole = acc_of(d)
+    posm = packed(ic)
+    lib = ctx._lib
+    h = C.c_void_p()
+    check(lib.nbody_hip_tree_create(ctx.handle, n, C.byref(h)))
+    try:
+        check(lib.nbody_hip_tree_build_packed(h, posm.data_ptr(), n))
+        out = torch.full((n, 4), float("nan"), dtype=torch.float32, device="cuda")
+        cuts = [(n * k) // parts for k in range(parts + 1)]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            check(lib.nbody_hip_tree_compute_forces_packed(h, lo, hi - lo, 0.5, 1.0, 0.05, out.data_ptr()))
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()            # every row written by some range
+        assert (got[:, 3] == 0).all()
+        if n > 262144 // 4:                       # plain walk on both sides: bit for bit
+            assert np.array_equal(got[:, :3], whole)
+        else:                                     # the split walk's replica count depends on the range length
+            assert rel_err(got[:, :3], whole).max() < 2e-6
+        with pytest.raises(nb.ValidationException):
+            check(lib.nbody_hip_tree_compute_forces_packed(h, n - 5, 6, 0.5, 1.0, 0.05, out.data_ptr()))
+        check(lib.nbody_hip_tree_compute_forces_packed(h, n, 0, 0.5, 1.0, 0.05, out.data_ptr()))  # empty range: no-op
+    finally:
+        lib.nbody_hip_tree_destroy(h)

@@ -64,7 +64,7 @@ def test_reference_example_force_methods(tmp_path):
 
 # the multi-GPU code paths (process group, RCCL all-gather, barrier, all-reduce) with ONE rank
 # under torch.distributed.run: everything except the cross-rank traffic itself
-@pytest.mark.parametrize("workload,n", [("direct", 65536), ("hash", 131072)])
+@pytest.mark.parametrize("workload,n", [("direct", 65536), ("hash", 131072), ("bh", 100000)])
 def test_sharded_bench_rehearsal_one_rank(workload, n):
     import json
     import socket

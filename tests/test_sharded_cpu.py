@@ -65,6 +65,17 @@ class OracleBackend:
         w[np.arange(p.shape[0])[ok], idx[ok]] = 0.0
         return ke, float(-0.5 * G * (p[:, 3] * w.sum(1)).sum())
 
+    def tree_forces(self, posm_all, first, count, theta, G, eps, out_all):
+        # the oracle's tree for the bodies [first, first + count) taken in index order (which bodies
+        # a rank walks does not change any body's result)
+        p = posm_all.numpy()
+        c = np.ascontiguousarray
+        idx = np.arange(first, first + count)
+        eps2 = float(np.float32(eps) * np.float32(eps))
+        bx, by, bz, _, _ = self.o.barnes_hut_forces(c(p[:, 0]), c(p[:, 1]), c(p[:, 2]), c(p[:, 3]), idx, G, eps2, theta)
+        o = out_all.numpy()
+        o[idx, 0], o[idx, 1], o[idx, 2], o[idx, 3] = bx, by, bz, 0
+
     # -- spatial hash (z-slab path) -------------------------------------------------------------
     def bbox(self, posm):
         p = posm.numpy()
@@ -252,3 +263,53 @@ def test_pair_schedule_covers_every_pair_once(nb):
         # balance at even W: every rank evaluates the same number of body pairs
         work = [sum((i1 - i0) * (j1 - j0) for i0, i1, _, j0, j1 in pair_schedule(W, r, 8)) for r in range(W)]
         assert max(work) - min(work) <= 0, (W, work)
+
+
+def _tree_worker(rank, world, port, n, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nbody_amd
+        from nbody_amd.distributed import ShardedTreeSystem
+        ic = nbody_amd.ic.plummer(n, seed=6)
+        sysm = ShardedTreeSystem(ic, 1.0, 0.02, 0.5, backend=OracleBackend(), device="cpu")
+        sysm.initial_forces()
+        for _ in range(steps):
+            sysm.step(1e-3)
+        pos, vel, acc = (sysm.gather_global(k) for k in ("posm", "vel", "acc"))
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"t{world}.npz"), pos=pos, vel=vel, acc=acc)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 500), (3, 501)])
+def test_sharded_tree_matches_single_process(tmp_path, world, n, oracle, nb):
+    """replicated tree + partitioned walk + reduce == the single-process Barnes-Hut run"""
+    from oracle_bind import host_state
+    steps, dt, eps, theta = 2, 1e-3, 0.02, 0.5
+    mp.spawn(_tree_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / f"t{world}.npz")
+    s = host_state(nb.ic.plummer(n, seed=6))
+    eps2 = float(np.float32(eps) * np.float32(eps))
+
+    def forces():
+        return oracle.barnes_hut_forces(s["pos_x"], s["pos_y"], s["pos_z"], s["mass"], np.arange(n), 1.0, eps2, theta)[:3]
+
+    s["acc_x"], s["acc_y"], s["acc_z"] = forces()
+    for _ in range(steps):
+        for k in ("x", "y", "z"):
+            s["acc_old_" + k] = s["acc_" + k].copy()
+        oracle.update_positions(s, dt)
+        s["acc_x"], s["acc_y"], s["acc_z"] = forces()
+        oracle.update_velocities(s, dt)
+    for col, k in enumerate(("pos_x", "pos_y", "pos_z")):
+        assert np.allclose(got["pos"][:, col], s[k], rtol=1e-6, atol=1e-6), k
+    for col, k in enumerate(("vel_x", "vel_y", "vel_z")):
+        assert np.allclose(got["vel"][:, col], s[k], rtol=1e-5, atol=1e-6), k
+    for col, k in enumerate(("acc_x", "acc_y", "acc_z")):
+        assert np.allclose(got["acc"][:, col], s[k], rtol=1e-5, atol=1e-6), k

@@ -136,3 +136,47 @@ def test_sharded_hash_on_gpu(tmp_path, world, cutoff, oracle, nb):
     # dv = dt/2 (a_old + a_new) per step inherits the 1e-5 * |a| force tolerance
     for col, k in enumerate(("vel_x", "vel_y", "vel_z")):
         assert np.allclose(got["vel"][:, col], s[k], rtol=1e-5, atol=1e-5 * scale * dt * steps + 1e-6), k
+
+
+def _tree_worker(rank, world, port, n, steps, out_dir):
+    _setup(rank, world, port)
+    try:
+        import nbody_amd
+        from nbody_amd.distributed import HipBackend, ShardedTreeSystem
+        ic = nbody_amd.ic.two_galaxies(n, seed=9)
+        sysm = ShardedTreeSystem(ic, 1.0, 0.05, 0.5, backend=HipBackend(nbody_amd.Context()))
+        sysm.initial_forces()
+        for _ in range(steps):
+            sysm.step(1e-3)
+        pos, vel, acc = (sysm.gather_global(k) for k in ("posm", "vel", "acc"))
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "t.npz"), pos=pos, vel=vel, acc=acc)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 600000), (3, 40001)])
+def test_sharded_tree_on_gpu(tmp_path, world, n, nb, ctx):
+    """replicated tree + partitioned walk on 2-3 ranks == the single-GPU ParticleSystem-style run
+    (bit for bit when both sides use the plain walk, i.e. ranges above 65,536 bodies)"""
+    from gpu_util import to_device
+    steps = 2
+    mp.spawn(_tree_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "t.npz")
+    ic = nb.ic.two_galaxies(n, seed=9)
+    d, _ = to_device(nb, ic)
+    fc = nb.BarnesHutCalculator(0.5)
+    fc.setSofteningParameter(0.05)
+    integ = nb.Integrator()
+    fc.computeForces(d)
+    for _ in range(steps):
+        integ.integrate(d, fc, 1e-3)
+    ref_pos = np.stack([d.pos_x.cpu().numpy(), d.pos_y.cpu().numpy(), d.pos_z.cpu().numpy()], 1)
+    ref_acc = np.stack([d.acc_x.cpu().numpy(), d.acc_y.cpu().numpy(), d.acc_z.cpu().numpy()], 1)
+    if n // world > 131072:
+        assert np.array_equal(got["acc"][:, :3], ref_acc)
+        assert np.array_equal(got["pos"][:, :3], ref_pos)
+    else:
+        err = np.linalg.norm(got["acc"][:, :3] - ref_acc, axis=1) / np.linalg.norm(ref_acc, axis=1)
+        assert err.max() < 1e-5
+        assert np.allclose(got["pos"][:, :3], ref_pos, rtol=1e-6, atol=1e-6)
