@@ -273,7 +273,7 @@ static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, 
                      NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
 }
 
-// symmetric kernel worth it from here (measured, tools/test_sym3.py): below, the one-sided kernel
+// symmetric kernel worth it from here (measured, tools/sweep_sym_sizes.py): below, the one-sided kernel
 bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n) {
   if (ctx->tune_variant == 3) return true;
   return ctx->tune_variant < 0 && n >= 32768;
