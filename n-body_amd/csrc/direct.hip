@@ -60,27 +60,51 @@ __device__ __forceinline__ void interact(const float4 s, const float (&xi)[R], c
   }
 }
 
-// Packed form: two targets per v_pk_*_f32 instruction (R even).
-template <int R>
-__device__ __forceinline__ void interact_pk(const float4 s, const f2 (&xi)[R / 2],
+// Packed form: two targets per v_pk_*_f32 instruction (R even), NS sources per call.  Written in
+// phases over the NS * R/2 independent chains (differences and r^2, then every v_rsq, then the
+// factors, then the sums): left to itself the compiler finishes one chain after the other and pads
+// the dependent packed operations with hazard nops.
+template <int R, int NS>
+__device__ __forceinline__ void interact_pk(const float4 (&s)[NS], const f2 (&xi)[R / 2],
                                             const f2 (&yi)[R / 2], const f2 (&zi)[R / 2],
                                             f2 (&ax)[R / 2], f2 (&ay)[R / 2], f2 (&az)[R / 2],
                                             const float eps2) {
-  const f2 sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z}, sm = {s.w, s.w};
+  constexpr int H = R / 2;
   const f2 e2 = {eps2, eps2};
+  f2 dx[NS * H], dy[NS * H], dz[NS * H], g[NS * H];
 #pragma unroll
-  for (int r = 0; r < R / 2; r++) {
-    const f2 dx = sx - xi[r];
-    const f2 dy = sy - yi[r];
-    const f2 dz = sz - zi[r];
-    const f2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, e2)));
-    f2 inv;
-    inv.x = rsq(r2.x);
-    inv.y = rsq(r2.y);
-    const f2 f = (sm * inv) * (inv * inv);
-    ax[r] = __builtin_elementwise_fma(f, dx, ax[r]);
-    ay[r] = __builtin_elementwise_fma(f, dy, ay[r]);
-    az[r] = __builtin_elementwise_fma(f, dz, az[r]);
+  for (int q = 0; q < NS; q++) {
+    const f2 sx = {s[q].x, s[q].x}, sy = {s[q].y, s[q].y}, sz = {s[q].z, s[q].z};
+#pragma unroll
+    for (int r = 0; r < H; r++) {
+      const int c = q * H + r;
+      dx[c] = sx - xi[r]; dy[c] = sy - yi[r]; dz[c] = sz - zi[r];
+      g[c] = __builtin_elementwise_fma(dx[c], dx[c], __builtin_elementwise_fma(dy[c], dy[c], __builtin_elementwise_fma(dz[c], dz[c], e2)));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NS * H; c++) {
+    g[c].x = rsq(g[c].x);
+    g[c].y = rsq(g[c].y);
+  }
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    const f2 sm = {s[q].w, s[q].w};
+#pragma unroll
+    for (int r = 0; r < H; r++) {
+      const int c = q * H + r;
+      g[c] = (sm * g[c]) * (g[c] * g[c]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+#pragma unroll
+    for (int r = 0; r < H; r++) {
+      const int c = q * H + r;
+      ax[r] = __builtin_elementwise_fma(g[c], dx[c], ax[r]);
+      ay[r] = __builtin_elementwise_fma(g[c], dy[c], ay[r]);
+      az[r] = __builtin_elementwise_fma(g[c], dz[c], az[r]);
+    }
   }
 }
 
@@ -157,8 +181,11 @@ __global__ __launch_bounds__(kBlock) void direct_kernel(const float4* __restrict
           pz[r] = f2{zi[2 * r], zi[2 * r + 1]};
           ax[r] = ay[r] = az[r] = f2{0.f, 0.f};
         }
-#pragma unroll 8
-        for (int k = 0; k < TS; k++) interact_pk<R>(tile[b][k], px, py, pz, ax, ay, az, eps2);
+#pragma unroll 4
+        for (int k = 0; k < TS; k += 2) {
+          const float4 two[2] = {tile[b][k], tile[b][k + 1]};
+          interact_pk<R, 2>(two, px, py, pz, ax, ay, az, eps2);
+        }
 #pragma unroll
         for (int r = 0; r < R / 2; r++) {
           sx[2 * r] += (double)ax[r].x; sx[2 * r + 1] += (double)ax[r].y;
