@@ -250,14 +250,37 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
         for (int kb = k0; kb < k1; kb += 64) {
           float ax = 0.f, ay = 0.f, az = 0.f;
           const int ke = min(kb + 64, k1);
-#pragma unroll 4
-          for (int k = kb; k < ke; k++) {
+          // four sources per round: the four LDS reads are in flight together; each source keeps its
+          // own test, so that the expensive part (rsq, factor, sums) is skipped by the whole wave when
+          // no lane is inside its cutoff (frequent: half of the scanned cells are not neighbours)
+          int k = kb;
+          for (; k + 4 <= ke; k += 4) {
+            float4 s[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) s[q] = tile[b][k + q];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const float dx = s[q].x - pi.x, dy = s[q].y - pi.y, dz = s[q].z - pi.z;
+              const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+              bool ok = d2 < cutoff2;                           // :131, unsoftened distance
+              if (GUARD) ok = ok && (d2 > 0.f);                 // coincident / self: contributes 0
+              if (STRICT) ok = ok && (abs(tile_cx[b][k + q] - cxi) <= 1);
+              if (ok) {
+                const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+                const float f = (s[q].w * inv) * (inv * inv);
+                ax = __builtin_fmaf(f, dx, ax);
+                ay = __builtin_fmaf(f, dy, ay);
+                az = __builtin_fmaf(f, dz, az);
+              }
+            }
+          }
+          for (; k < ke; k++) {
             const float4 s = tile[b][k];
             const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
             const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
             const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
-            bool ok = d2 < cutoff2;                       // :131, unsoftened distance
-            if (GUARD) ok = ok && (d2 > 0.f);             // coincident / self: contributes 0
+            bool ok = d2 < cutoff2;
+            if (GUARD) ok = ok && (d2 > 0.f);
             if (STRICT) ok = ok && (abs(tile_cx[b][k] - cxi) <= 1);
             const float f = ok ? (s.w * inv) * (inv * inv) : 0.f;
             ax = __builtin_fmaf(f, dx, ax);
