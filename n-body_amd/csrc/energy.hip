@@ -64,6 +64,10 @@ __global__ __launch_bounds__(kBlock) void final_sum_kernel(const double* __restr
 // sum_i m_i * sum_{j in split, j != i} m_j / sqrt(r_ij^2 + eps^2)
 // Targets and sources may be different arrays (one shard against the gathered bodies): target i
 // is source number self_offset + i (no such source when the sets are disjoint).
+// TRI (targets == sources, one body set): every unordered pair once, from its lower index -- the
+// reference's j > i loop (integrator.cu:97) at tile granularity: source tiles that lie entirely
+// below the block's own bodies are not even loaded.  Half the pair evaluations of the ordered sum.
+template <bool TRI>
 __global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restrict__ tgt, int nt,
                                                            long long self_offset,
                                                            const float4* __restrict__ posm, int n,
@@ -84,8 +88,10 @@ __global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restr
     return j < j1 ? posm[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   double total = 0.0;
-  float4 pre = load_src(j0 + tid);
-  for (int t = 0; t < ntiles; t++) {
+  // first tile that reaches the block's own bodies (block-uniform)
+  const int tstart = TRI ? max(0, ((int)blockIdx.x * kBlock - j0) / PTS) : 0;
+  float4 pre = load_src(j0 + tstart * PTS + tid);
+  for (int t = tstart; t < ntiles; t++) {
     const int b = t & 1;
     tile[b][tid] = pre;
     __syncthreads();
@@ -101,7 +107,8 @@ __global__ __launch_bounds__(kBlock) void potential_kernel(const float4* __restr
       // r2 == 0 only when eps == 0 and the bodies coincide: the reference divides by zero there;
       // here such a pair contributes nothing.
       const float inv = __builtin_amdgcn_rsqf(r2);
-      acc += ((jb + k != i) & (r2 > 0.f)) ? s.w * inv : 0.f;
+      const bool take = TRI ? (jb + k > i) : (jb + k != i);
+      acc += (take & (r2 > 0.f)) ? s.w * inv : 0.f;
     }
     total += (double)acc;
   }
@@ -184,12 +191,12 @@ extern "C" int nbody_hip_potential_energy_f64(nbody_hip_ctx* ctx, const nbody_pa
   const size_t np = (size_t)bx * splits;
   if (int rc = ctx->reduce.reserve((np + 1) * sizeof(double))) return rc;
   double* partial = static_cast<double*>(ctx->reduce.ptr);
-  hipLaunchKernelGGL(potential_kernel, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, posm, (int)n, 0LL,
+  hipLaunchKernelGGL(potential_kernel<true>, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, posm, (int)n, 0LL,
                      posm, (int)n, tiles_per_split * PTS, eps * eps, partial);
   NBH_LAUNCH_CHECK();
-  // ordered pairs counted twice -> * 0.5; sign and G here (integrator.cu:102: pe -= G mi mj / r)
+  // every unordered pair once; sign and G here (integrator.cu:102: pe -= G mi mj / r)
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial, (int)np,
-                     -0.5 * (double)G, partial + np);
+                     -(double)G, partial + np);
   NBH_LAUNCH_CHECK();
   NBH_HIP(hipMemcpyAsync(ctx->host_scalar, partial + np, sizeof(double), hipMemcpyDeviceToHost,
                          ctx->stream));
@@ -251,7 +258,7 @@ extern "C" int nbody_hip_energies_packed(nbody_hip_ctx* ctx, const nbody_float4*
   hipLaunchKernelGGL(kinetic_packed_kernel, dim3(kb), dim3(kBlock), 0, ctx->stream, tp, tv, n_targets, kpart);
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, kpart, kb, 1.0, res);
   if (np > 0) {
-    hipLaunchKernelGGL(potential_kernel, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, tp, (int)n_targets,
+    hipLaunchKernelGGL(potential_kernel<false>, dim3(bx, splits), dim3(kBlock), 0, ctx->stream, tp, (int)n_targets,
                        self_offset, sp, (int)n_sources, tiles_per_split * PTS, eps * eps, partial);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial, (int)np,
                        -0.5 * (double)G, res + 1);

@@ -247,7 +247,7 @@ def test_shard_energies_sum_to_whole(nb, oracle, ctx, n, parts):
         k, p = b.energies(posm[lo:hi], vel[lo:hi], int(lo), posm, 1.3, 0.02)
         ke, pe = ke + k, pe + p
     assert abs(ke - ke_ref) <= 1e-12 * abs(ke_ref)
-    assert abs(pe - pe_ref) <= 1e-9 * abs(pe_ref)      # same fp32 terms, fp64 sums in another grouping
+    assert abs(pe - pe_ref) <= 1e-7 * abs(pe_ref)      # ordered vs unordered pair sums: fp32 terms round differently
     # disjoint sets: no self pair anywhere; the two directions agree
     a, c = posm[: n // 2], posm[n // 2:]
     _, pac = b.energies(a, vel[: n // 2], -n, c, 1.0, 0.02)
