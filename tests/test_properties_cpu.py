@@ -1,0 +1,168 @@
+"""The reference's RapidCheck properties (RC_GTEST_PROP) restated with hypothesis, for the parts that
+need no GPU: the oracle's pair force (tests/test_force_calculation.cpp:101-180), the validators
+(tests/test_validation.cpp:82-197), the host initialisers (tests/test_particle_data.cpp:117-204) and
+the checkpoint round trip (tests/test_serialization.cpp:119-168).  Same preconditions, same
+assertions; the GPU-side twins are in tests/test_properties_gpu.py."""
+import io
+import math
+
+import numpy as np
+import pytest
+from hypothesis import assume, given, settings
+from hypothesis import strategies as st
+
+def F(lo, hi):
+    """float32 values in [lo, hi] (bounds rounded to float32)"""
+    return st.floats(min_value=float(np.float32(lo)), max_value=float(np.float32(hi)), width=32)
+
+
+coord = F(-99.0, 99.0)
+SET = settings(max_examples=100, deadline=None)
+
+
+# ---- Property 1: force calculation correctness (computeGravitationalForceCPU restated) ----------
+
+@SET
+@given(coord, coord, coord, coord, coord, coord, F(0.02, 99.0), F(0.02, 99.0))
+def test_force_magnitude_correctness(oracle, x1, y1, z1, x2, y2, z2, m1, m2):
+    r = math.dist((x1, y1, z1), (x2, y2, z2))
+    assume(r > 0.2)  # the reference asks r > 0.01, where its own 1 % bound does not hold (eps = 0.01)
+    f = np.array(oracle.pair_force((x1, y1, z1), (x2, y2, z2), m1, m2, 1.0, 0.01), np.float64)
+    expected = m2 / (r * r + 0.01 * 0.01)            # :123 (m1 does not enter: acceleration of body 1)
+    assert abs(np.linalg.norm(f) - expected) / expected < 0.01
+
+
+@SET
+@given(coord, coord, coord, coord, coord, coord)
+def test_force_direction_correctness(oracle, x1, y1, z1, x2, y2, z2):
+    d = np.array([x2 - x1, y2 - y1, z2 - z1], np.float64)
+    r = np.linalg.norm(d)
+    assume(r > 0.01)
+    f = np.array(oracle.pair_force((x1, y1, z1), (x2, y2, z2), 1.0, 1.0, 1.0, 0.01), np.float64)
+    assert np.dot(d / r, f / np.linalg.norm(f)) > 0.999  # :151
+
+
+@SET
+@given(coord, coord, coord, coord, coord, coord, F(0.0011, 9.9))
+def test_softening_finiteness(oracle, x1, y1, z1, x2, y2, z2, eps):
+    f = np.array(oracle.pair_force((x1, y1, z1), (x2, y2, z2), 1.0, 1.0, 1.0, eps), np.float64)
+    assert np.isfinite(f).all() and np.linalg.norm(f) < 1e10  # :174-178 (also for coincident points)
+
+
+# ---- Property: validation (tests/test_validation.cpp:82-197) ------------------------------------
+
+@SET
+@given(st.integers(min_value=-(2 ** 31), max_value=0))
+def test_rejects_non_positive_particle_count(nb, count):
+    from nbody_amd import api
+    # the reference casts to size_t: a negative int becomes a huge count, 0 stays 0 -- both rejected
+    with pytest.raises(nb.ValidationException):
+        api.validateParticleCountRange(count % (1 << 64))
+
+
+@SET
+@given(st.one_of(st.floats(max_value=0.0, allow_nan=False), st.floats(min_value=1.0000001, allow_nan=False),
+                 st.just(float("nan")), st.just(float("inf")), st.just(float("-inf"))))
+def test_rejects_invalid_time_step(nb, dt):
+    from nbody_amd import api
+    with pytest.raises(nb.ValidationException):
+        api.validateTimeStep(dt)
+
+
+def test_rejects_nan_softening(nb):
+    from nbody_amd import api
+    for bad in (float("nan"), float("inf"), -1e-30):
+        with pytest.raises(nb.ValidationException):
+            api.validateSoftening(bad)
+
+
+@SET
+@given(st.one_of(st.floats(max_value=-1e-6, allow_nan=False), st.floats(min_value=2.000001, allow_nan=False),
+                 st.just(float("nan")), st.just(float("inf"))))
+def test_rejects_out_of_range_theta(nb, theta):
+    from nbody_amd import api
+    with pytest.raises(nb.ValidationException):
+        api.validateTheta(theta)
+
+
+@SET
+@given(st.integers(1, 1000000), st.floats(0.00011, 1.0), st.floats(0.0, 9.99), st.floats(0.0, 2.0))
+def test_accepts_valid_parameters(nb, count, dt, softening, theta):
+    from nbody_amd import api
+    api.validateParticleCountRange(count)
+    api.validateTimeStep(dt)
+    api.validateSoftening(softening)
+    api.validateTheta(theta)
+    api.validateSimulationConfig(nb.SimulationConfig(particle_count=count, dt=dt, softening=softening,
+                                                     barnes_hut_theta=theta, force_method=nb.ForceMethod.BARNES_HUT))
+
+
+def test_state_unchanged_after_rejection(nb):
+    from nbody_amd import api
+    cfg = nb.SimulationConfig()
+    before = dict(vars(cfg))
+    with pytest.raises(nb.ValidationException) as e:
+        api.validateTimeStep(-1.0)
+    assert "Time step" in str(e.value)      # the reference prefixes "Validation Error: " in what()
+    assert vars(cfg) == before
+
+
+# ---- Property: initialiser bounds (tests/test_particle_data.cpp:117-204) -------------------------
+
+@SET
+@given(coord, coord, coord, coord, coord, coord, st.integers(0, 2 ** 31 - 1))
+def test_uniform_bounds_property(nb, ax, ay, az, bx, by, bz, seed):
+    lo, hi = (min(ax, bx), min(ay, by), min(az, bz)), (max(ax, bx), max(ay, by), max(az, bz))
+    assume(all(h > l for l, h in zip(lo, hi)))
+    h = nb.ParticleData()
+    nb.ParticleDataManager.allocateHost(h, 100)
+    nb.ParticleInitializer.initUniform(h, nb.UniformDistParams(lo, hi, 1.0, 1.0), seed)
+    for k, f in enumerate(("pos_x", "pos_y", "pos_z")):
+        a = getattr(h, f)
+        assert (a >= np.float32(lo[k])).all() and (a <= np.float32(hi[k])).all()
+    assert (h.mass == 1.0).all() and not h.vel_x.any() and not h.acc_z.any()
+
+
+@SET
+@given(coord, coord, coord, F(0.11, 99.0), st.integers(0, 2 ** 31 - 1))
+def test_spherical_bounds_property(nb, cx, cy, cz, radius, seed):
+    h = nb.ParticleData()
+    nb.ParticleDataManager.allocateHost(h, 100)
+    nb.ParticleInitializer.initSpherical(h, nb.SphericalDistParams((cx, cy, cz), radius, 1.0, 2.0), seed)
+    d = np.sqrt((h.pos_x.astype(np.float64) - np.float32(cx)) ** 2 + (h.pos_y.astype(np.float64) - np.float32(cy)) ** 2
+                + (h.pos_z.astype(np.float64) - np.float32(cz)) ** 2)
+    assert (d <= radius + 0.01).all()                       # :170
+    assert (h.mass >= 1.0).all() and (h.mass <= 2.0).all()
+
+
+@SET
+@given(coord, coord, coord, F(0.11, 99.0), F(0.011, 9.9), st.integers(0, 2 ** 31 - 1))
+def test_disk_bounds_property(nb, cx, cy, cz, radius, thickness, seed):
+    h = nb.ParticleData()
+    nb.ParticleDataManager.allocateHost(h, 100)
+    nb.ParticleInitializer.initDisk(h, nb.DiskDistParams((cx, cy, cz), radius, thickness), seed)
+    dx, dy = h.pos_x.astype(np.float64) - np.float32(cx), h.pos_y.astype(np.float64) - np.float32(cy)
+    assert (np.sqrt(dx * dx + dy * dy) <= radius + 0.01).all()                      # :202
+    assert (np.abs(h.pos_z.astype(np.float64) - np.float32(cz)) <= thickness / 2 + 0.01).all()  # :203
+    # tangential velocities: v . r = 0 (particle_init.cu:350-352)
+    assert np.abs(h.vel_x * dx + h.vel_y * dy).max() <= 1e-3 * (1.0 + np.abs(h.vel_x).max() * radius)
+
+
+# ---- Property: serialization round trip (tests/test_serialization.cpp:119-168) -------------------
+
+@SET
+@given(st.integers(1, 100), F(0.0, 999.0), F(0.00011, 0.99),
+       F(0.001, 99.0), F(0.0, 9.9), st.integers(0, 2), st.integers(0, 2 ** 31 - 1))
+def test_round_trip_preserves_state(nb, count, sim_time, dt, G, softening, method, seed):
+    rng = np.random.default_rng(seed)
+    s = nb.SimulationState(particle_count=count, simulation_time=sim_time, dt=dt, G=G, softening=softening,
+                           force_method=nb.ForceMethod(method))
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        setattr(s, k, rng.uniform(-100, 100, count).astype(np.float32))
+    s.mass = rng.uniform(0.1, 10, count).astype(np.float32)
+    buf = io.BytesIO()
+    nb.Serializer.save(buf, s)
+    buf.seek(0)
+    assert nb.Serializer.readHeader(buf)["particle_count"] == count
+    buf.seek(0)
+    assert nb.Serializer.load(buf) == s
