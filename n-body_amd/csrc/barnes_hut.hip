@@ -279,6 +279,14 @@ __global__ __launch_bounds__(kTopBlock) void top_monopole_kernel(int top_level,
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// |d|^2 of the walk: dx*dx, then two fused multiply-adds -- the chain nvcc's default contraction makes
+// of force_barnes_hut.cu:165; oracle/nbody_oracle.c (bh_dist2) forms it identically, so both sides
+// open exactly the same nodes.  (Everything else in the walk stays uncontracted except the
+// explicit fma of the running sums, which takes no decision.)
+__device__ __forceinline__ float bh_dist2(float dx, float dy, float dz) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
 // ---------------------------------------------------------------------------------------
 // Traversal.  block = 256 = 4 independent waves; wave w of block b walks the tree for sorted
 // bodies [b*256 + w*64, +64).
@@ -352,37 +360,39 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
           // Only in the latency-bound split walk: measured 10% faster there, 8-15% slower at 1M
           // bodies, where the scalar fetch of the body overlaps with other waves.
           const float dx = nd.cx - pi.x, dy = nd.cy - pi.y, dz = nd.cz - pi.z;
-          const float d2 = dx * dx + dy * dy + dz * dz;
+          const float d2 = bh_dist2(dx, dy, dz);
           const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
           bool ok = in && (nd.first != t);
           if (GUARD) ok = ok && (d2 > 0.f);
           const float f = ok ? (nd.mass * inv) * (inv * inv) : 0.f;
-          ax += f * dx; ay += f * dy; az += f * dz;
+          ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
           continue;
         }
         for (int q = nd.first; q < nd.first + nd.count; q++) {
           const float4 s = sorted[q];
           const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
-          const float d2 = dx * dx + dy * dy + dz * dz;
+          const float d2 = bh_dist2(dx, dy, dz);
           const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
           bool ok = in && (q != t);
           if (GUARD) ok = ok && (d2 > 0.f);
           const float f = ok ? (s.w * inv) * (inv * inv) : 0.f;
-          ax += f * dx; ay += f * dy; az += f * dz;
+          ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
         }
         continue;
       }
       const float dx = nd.cx - pi.x, dy = nd.cy - pi.y, dz = nd.cz - pi.z;
-      const float dist2 = dx * dx + dy * dy + dz * dz + eps2;  // :165
+      const float dist2 = bh_dist2(dx, dy, dz) + eps2;  // :165
       // :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the same
       // inequality without the IEEE division sequence; the oracle uses the same form
-      const bool accept = in && (nd.size2 < theta2 * dist2);
-      if (accept && mine) {  // skipped by the whole wave when every lane opens the node (common)
+      const bool far = nd.size2 < theta2 * dist2;
+      if (in && far && mine) {  // skipped by the whole wave when every lane opens the node (common)
         const float inv = __builtin_amdgcn_rsqf(dist2);
         const float f = (nd.mass * inv) * (inv * inv);
-        ax += f * dx; ay += f * dy; az += f * dz;
+        ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
       }
-      const unsigned long long O = __ballot(in && !accept);
+      // lanes of the group's mask that must open the node: scalar mask arithmetic on the compare
+      // result (a ballot of `in && !far` goes through a VGPR and a second compare)
+      const unsigned long long O = M & ~__ballot(far);
       if (O != 0ull && descend) {
         if (lane == 0)
           stk[w][sp] = make_int4((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28),

@@ -601,6 +601,12 @@ static int otree_build(OTree* t, int first, int count, int level) {
 }
 
 typedef struct { uint32_t key; int idx; } KeyIdx;
+/* |d|^2 of the Barnes-Hut walk as the device code forms it: dx*dx, then two fused multiply-adds
+ * (force_barnes_hut.cu:165 `dx*dx + dy*dy + dz*dz` -- nvcc contracts exactly this chain with its
+ * default -fmad=true; the HIP walk writes the same chain explicitly, so the opening decisions of
+ * both sides are taken on bit-identical distances). */
+static inline float bh_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+
 static int cmp_keyidx(const void* a, const void* b) {
   const KeyIdx* p = (const KeyIdx*)a; const KeyIdx* q = (const KeyIdx*)b;
   if (p->key != q->key) return p->key < q->key ? -1 : 1;
@@ -659,7 +665,7 @@ ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y
           int j = order[q];
           if (j == i) continue; /* :175 self */
           float dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
-          float dist2 = dx * dx + dy * dy + dz * dz + eps2;
+          float dist2 = bh_dist2(dx, dy, dz) + eps2;
           float inv = 1.0f / sqrtf(dist2);
           float f = G * m[j] * (inv * inv * inv);
           a0 += (double)(f * dx); a1 += (double)(f * dy); a2 += (double)(f * dz);
@@ -667,7 +673,7 @@ ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y
         continue;
       }
       float dx = (float)nd->mx - xi, dy = (float)nd->my - yi, dz = (float)nd->mz - zi;
-      float dist2 = dx * dx + dy * dy + dz * dz + eps2; /* :165 */
+      float dist2 = bh_dist2(dx, dy, dz) + eps2; /* :165 */
       float size = 2.0f * nd->half;
       float size2 = size * size;                         /* :168 */
       /* :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the

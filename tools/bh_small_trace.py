@@ -1,4 +1,4 @@
-"""Barnes-Hut steps at a launch-bound size, for rocprofv3 --kernel-trace --stats."""
+"""Barnes-Hut steps for rocprofv3 (kernel trace or counters): bh_small_trace.py [N] [steps] [ic name]"""
 import os
 import sys
 
@@ -12,7 +12,8 @@ from gpu_util import to_device  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-d, h = to_device(nb, nb.ic.plummer(n, seed=1))
+icname = sys.argv[3] if len(sys.argv) > 3 else "plummer"
+d, h = to_device(nb, getattr(nb.ic, icname)(n, seed=1))
 fc = nb.BarnesHutCalculator(0.5)
 fc.setSofteningParameter(0.05)
 integ = nb.Integrator()
