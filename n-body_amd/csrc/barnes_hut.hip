@@ -345,7 +345,8 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     for (int k = 0; k < 8; k++) {
       if (k >= cn) break;  // wave-uniform
       const NodeRec nd = rec[k];
-      if (nd.mass == 0.0f) continue;   // :161-162 massless node
+      // (a massless node, :161-162, needs no test of its own: it contributes m * g = 0 if accepted and
+      // only massless descendants if opened)
       bool mine = true, descend = true;  // wave-uniform
       if (SPLIT && c0 + k < split_end) {
         mine = ((c0 + k) & rmask) == replica;
