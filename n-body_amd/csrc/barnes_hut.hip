@@ -36,6 +36,9 @@
 
 #include "common.h"
 
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                             rocprim::default_config, nbh::kSortMergeLimit>;
+
 namespace nbh {
 
 constexpr int kMaxDepth = 10;      // 30-bit Morton keys
@@ -538,7 +541,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
   if (e == hipSuccess) {
     size_t t1 = 0, t2 = 0;
-    e = rocprim::radix_sort_pairs(nullptr, t1, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n, 0,
+    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n, 0,
                                   30, ctx->stream);
     if (e == hipSuccess)
       e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, nflag, rocprim::plus<int>(), ctx->stream);
@@ -593,7 +596,7 @@ static int tree_build_packed(nbody_hip_tree* g, const float4* posm, size_t n) {
                      g->d_keys_a, g->d_idx_a);
   NBH_LAUNCH_CHECK();
   size_t tmp = g->tmp_bytes;
-  NBH_HIP(rocprim::radix_sort_pairs(g->d_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
+  NBH_HIP(rocprim::radix_sort_pairs<SortConfig>(g->d_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
                                     0, 30, st));
   hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
   NBH_LAUNCH_CHECK();

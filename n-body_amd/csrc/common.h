@@ -2,6 +2,10 @@
 // gfx950 (MI355X) only; wave64; no CUDA compatibility layer.
 #pragma once
 
+#ifndef NBH_SORT_MERGE_LIMIT
+#define NBH_SORT_MERGE_LIMIT (300 * 1000)
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -16,6 +20,10 @@ namespace nbh {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
 constexpr int kNumCU = 256;   // MI355X
+// rocPRIM's radix sort switches from its merge-sort path (2 launches per doubling: 22 at 2^20 keys)
+// to Onesweep above `merge_sort_limit` (default 2^20, i.e. exactly NOT at the BASELINE size); measured:
+// merge sort wins at 262,144 keys (0.24 vs 0.26 ms tree build), Onesweep from 524,288 (0.14 vs 0.18 ms)
+constexpr size_t kSortMergeLimit = NBH_SORT_MERGE_LIMIT;
 
 void set_error(const char* fmt, ...);
 int fail(nbody_hip_status code, const char* file, int line, const char* fmt, ...);

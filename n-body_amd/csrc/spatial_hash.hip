@@ -32,6 +32,9 @@
 
 #include "common.h"
 
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                             rocprim::default_config, nbh::kSortMergeLimit>;
+
 namespace nbh {
 
 constexpr int HTS = 256;  // sources per LDS tile
@@ -374,7 +377,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_sorted), n * sizeof(float4));
   if (e == hipSuccess) {
     size_t tmp = 0;
-    e = rocprim::radix_sort_pairs(nullptr, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
+    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
                                   0, 32, ctx->stream);
     if (e == hipSuccess) {
       g->sort_tmp_bytes = tmp;
@@ -456,7 +459,7 @@ static int grid_build_packed(nbody_hip_grid* g, const float4* posm, size_t n, co
                      g->cell_size, g->d_keys_a, g->d_idx_a);
   NBH_LAUNCH_CHECK();
   size_t tmp = g->sort_tmp_bytes;
-  NBH_HIP(rocprim::radix_sort_pairs(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a,
+  NBH_HIP(rocprim::radix_sort_pairs<SortConfig>(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                                     g->d_idx_b, n, 0, bits_for(g->info.total), st));
   hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni,
                      g->d_sorted);
