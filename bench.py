@@ -48,6 +48,9 @@ def parse():
                          "ambiguous abbreviation of its own options)")
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; gloo + --one-device rehearses the N-rank path on ONE GPU")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant override (experiments)")
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane override")
     ap.add_argument("--splits", type=int, default=0, help="source splits override")
@@ -268,6 +271,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if a.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or a.force_sharded
     if sharded:
@@ -275,7 +280,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import nbody_amd as nb
     from nbody_amd.distributed import HipBackend, ShardedDirectSystem

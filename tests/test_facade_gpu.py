@@ -84,3 +84,28 @@ def test_sharded_bench_rehearsal_one_rank(workload, n):
     assert doc["n_gpus"] == 1 and doc["value"] > 0 and doc["steps"] == 2
     if workload == "direct":
         assert doc["metric"] == "pair_interactions_per_s" and "roofline" in doc
+
+
+# the N-rank branches of bench.py (shard-pair roofline leg, rank-0-only JSON, max over ranks) with TWO
+# ranks on the one test GPU: gloo transport, everything else as in the driver's N-GPU run
+@pytest.mark.parametrize("workload,n", [("direct", 100000), ("hash", 200000), ("bh", 150000)])
+def test_sharded_bench_rehearsal_two_ranks(workload, n):
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo",
+           "--one-device", "--workload", workload, "--bodies", str(n), "--kernel-iters", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["value"] > 0 and doc["steps"] == 2
+    if workload == "direct":
+        assert doc["metric"] == "pair_interactions_per_s" and doc["scaling"] == "strong"
+        assert "shard pair" in doc["roofline"]["kernel"] and doc["roofline"]["frac"] > 0
