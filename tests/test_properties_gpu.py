@@ -19,7 +19,7 @@ def F(lo, hi):
 
 
 coord = F(-99.0, 99.0)
-SET = settings(max_examples=40, deadline=None)
+SET = settings(max_examples=40, deadline=None, derandomize=True)
 
 
 def _two_bodies(nb, p1, p2, m1, m2, G, eps):
@@ -70,7 +70,7 @@ def test_softening_finiteness(nb, ctx, x1, y1, z1, x2, y2, z2, eps):
 # r = 5, m = G = 1 and v = sqrt(G m / 2r) -- a bound orbit whose total energy is 1e-8 of its parts
 # (KE + PE cancel), so its RELATIVE drift is ill-conditioned; here the orbit is the circular one
 # (v = sqrt(G m / 4r), E = -G m^2 / 4r) and the drift is asserted relative to that.
-@settings(max_examples=15, deadline=None)
+@settings(max_examples=15, deadline=None, derandomize=True)
 @given(F(1.0, 20.0), F(0.5, 5.0), F(0.5, 4.0))
 def test_energy_conservation_property(nb, ctx, radius, m, G):
     v = math.sqrt(G * m / (4.0 * radius))
@@ -95,13 +95,17 @@ def test_energy_conservation_property(nb, ctx, radius, m, G):
 
 
 # tests/test_serialization.cpp:171-220 on random small systems and every force method
-@settings(max_examples=9, deadline=None)
+@settings(max_examples=9, deadline=None, derandomize=True)
 @given(st.integers(2, 300), st.sampled_from([0, 1, 2]), st.integers(0, 10 ** 6))
 def test_pause_resume_preserves_state(nb, ctx, count, method, seed):
     cfg = nb.SimulationConfig(particle_count=count, force_method=nb.ForceMethod(method), dt=1e-3, softening=0.05,
                               init_distribution=nb.InitDistribution.SPHERICAL)
+    ic = nb.ic.sphere(count, seed=seed, radius=5.0)
+    rng = np.random.default_rng(seed)
+    for k in ("vel_x", "vel_y", "vel_z"):  # moving bodies: a cutoff method may see no neighbour at all
+        ic[k] = rng.normal(0.0, 0.5, count).astype(np.float32)
     ps = nb.ParticleSystem()
-    ps.initialize(cfg, initial_conditions=nb.ic.sphere(count, seed=seed, radius=5.0))
+    ps.initialize(cfg, initial_conditions=ic)
     for _ in range(3):
         ps.update(cfg.dt)
     before = ps.getState()
