@@ -276,7 +276,7 @@ static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, 
 // symmetric kernel worth it from here (measured, tools/sweep_sym_sizes.py): below, the one-sided kernel
 bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n) {
   if (ctx->tune_variant == 3) return true;
-  return ctx->tune_variant < 0 && n >= 32768;
+  return ctx->tune_variant < 0 && n >= 20480;
 }
 
 // bodies per lane R, measured (tools/sweep_sym_sizes.py, profiles/r01_sym_R_sweep.txt): the larger R,
@@ -287,7 +287,7 @@ static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
       ctx->tune_tpl == 16)
     return ctx->tune_tpl;
   if (two_sets) return n >= 49152 ? 16 : (n >= 16384 ? 8 : 4);
-  return n >= 786432 ? 16 : (n >= 98304 ? 8 : 4);
+  return n >= 786432 ? 16 : (n >= 98304 ? 8 : (n >= 30000 ? 4 : 2));
 }
 
 int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
