@@ -366,9 +366,9 @@ def main():
         eps2 = float(np.float32(eps) * np.float32(eps))
         if world == 1:
             # the step's force evaluation: all pairs of one body set -> nbh::direct_sym_kernel
-            r = a.tpl if a.tpl in (2, 4, 6, 8, 16) else (16 if n >= 786432 else 8 if n >= 98304 else 4 if n >= 30000 else 2)  # direct_sym.hip sym_R
+            r = a.tpl if a.tpl in (2, 4, 6, 8, 16) else (16 if n >= 786432 else 8 if n >= 28000 else 4)  # direct_sym.hip sym_R
             kname = (f"nbh::direct_sym_kernel<{r},false,{'true' if float(np.ptp(ic['mass'])) == 0.0 else 'false'}>"
-                     if n >= 20480 and a.variant in (-1, 3) else "nbh::direct_kernel (one-sided)")
+                     if n >= 12288 and a.variant in (-1, 3) else "nbh::direct_kernel (one-sided)")
             ms = nb.time_direct_packed(ctx, p, p, G, eps2, a.kernel_iters)
             pairs = float(n) * n
             alg_bytes = 16.0 * n + 16.0 * n

@@ -50,12 +50,17 @@ __device__ __forceinline__ float wave_rot1(float v) {
 // and the one that does not apply returns at once) the two multiplications g*m_j and g*m_i are
 // dropped from every pair (18 instead of 20 issue slots per unordered pair) and m0 is applied once
 // to the finished sums.
+#ifndef NBH_SYM_ATTR
+#define NBH_SYM_ATTR
+#endif
+constexpr int kSymBlocksPerCU = 16;  // workgroups aimed at per CU (tools/sweep_mid.py)
+constexpr int kSymMinChunks = 4;     // at least 4 chunks (256 J bodies) per workgroup
 constexpr float kFar = 1.0e18f;  // padding bodies sit here: (3e36)^-3/2 underflows to 0, no mass test needed
 
 template <int R, bool RECT, bool EQM>
-__global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __restrict__ posm, int n,
+__global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const float4* __restrict__ posm, int n,
                                                             const float4* __restrict__ posj, int nj,
-                                                            int NB, int NBJ, int offsets_per_split,
+                                                            int NB, int NBJ, int chunks_per_split,
                                                             double* __restrict__ acc64,
                                                             double* __restrict__ accj64,
                                                             size_t plane_i, size_t plane_j,
@@ -71,9 +76,13 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int A = blockIdx.x;
   const int D = RECT ? NBJ - 1 : NB / 2;     // largest partner offset
-  const int d0 = blockIdx.y * offsets_per_split;
-  const int d1 = min(D + 1, d0 + offsets_per_split);
-  if (d0 >= d1) return;
+  // the block's share of the flat list of (partner offset d, 64-body chunk c) pairs: splitting at
+  // chunk granularity (not whole partners) gives enough workgroups to fill the last round at
+  // mid sizes (65,536 bodies: 64 superblocks x 33 offsets is only two rounds of the chip)
+  constexpr int CPB = kBlock * R / 64;
+  const int q0 = blockIdx.y * chunks_per_split;
+  const int q1 = min((D + 1) * CPB, q0 + chunks_per_split);
+  if (q0 >= q1) return;
 
   // I side: R bodies per lane, packed in pairs
   f2 xi[R / 2], yi[R / 2], zi[R / 2], mi[R / 2];
@@ -85,22 +94,33 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
     if (i1 < n) p1 = posm[i1];
     xi[r] = f2{p0.x, p1.x}; yi[r] = f2{p0.y, p1.y}; zi[r] = f2{p0.z, p1.z}; mi[r] = f2{p0.w, p1.w};
   }
-  double sx[R], sy[R], sz[R];
+  // fp64 sums of the I side.  R = 16 would need 96 VGPRs for them and push the kernel past the 256
+  // architectural VGPRs (the rest are AGPRs, reached through copies -- measured: the fastest and
+  // the slowest variant, depending on the allocator's mood); they live in LDS there instead,
+  // touched once per 4 chunks, [component][r][thread] so that a wave's accesses are contiguous.
+  constexpr bool LACC = R >= 8;
+  constexpr int RR = LACC ? 1 : R;
+  __shared__ double lacc[LACC ? 3 * R * kBlock : 1];
+  double sx[RR], sy[RR], sz[RR];
+  if constexpr (LACC) {
 #pragma unroll
-  for (int r = 0; r < R; r++) sx[r] = sy[r] = sz[r] = 0.0;
+    for (int k = 0; k < 3 * R; k++) lacc[k * kBlock + tid] = 0.0;  // own slots only: no barrier needed
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; r++) sx[r] = sy[r] = sz[r] = 0.0;
+  }
   f2 ax[R / 2], ay[R / 2], az[R / 2];
 #pragma unroll
   for (int r = 0; r < R / 2; r++) ax[r] = ay[r] = az[r] = f2{0.f, 0.f};
   const f2 e2 = {eps2, eps2};
 
-  // flat list of chunks: (offset d, chunk c of the partner); S/64 chunks per partner
-  constexpr int CPB = S / 64;
+  // flat list of chunks: (offset d, chunk c of the partner); S/64 = CPB chunks per partner
   // partner d is skipped when the half ring would visit the pair twice (NB even, d = NB/2, upper half)
   auto partner_valid = [&](int d) { return RECT || !((NB % 2 == 0) && d == D && d > 0 && A >= D); };
-  const int nchunks = (d1 - d0) * CPB;
+  const int nchunks = q1 - q0;
 
   auto load_chunk = [&](int q) -> float4 {  // q-th chunk of this block's list, body `lane`
-    const int d = d0 + q / CPB, c = q % CPB;
+    const int d = (q0 + q) / CPB, c = (q0 + q) % CPB;
     const int B = RECT ? d : (A + d) % NB;
     const int j = B * S + c * 64 + lane;
     float4 p = make_float4(kFar, kFar, kFar, 0.f);
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
     return p;  // invalid partner / padding: zero mass, far away -> contributes nothing
   };
   auto flush_chunk = [&](int q) {  // one wave: combine the four waves' sums of chunk q, add to global
-    const int pd = d0 + q / CPB, pc = q % CPB;
+    const int pd = (q0 + q) / CPB, pc = (q0 + q) % CPB;
     if ((RECT || pd > 0) && partner_valid(pd)) {
       const int j = (RECT ? pd : (A + pd) % NB) * S + pc * 64 + lane;
       const int sb = q & 1;
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
   for (int q = 0; q < nchunks; q++) {
     const float4 jcur = jnext;
     if (q + 1 < nchunks) jnext = load_chunk(q + 1);  // next chunk in flight under the math
-    const int d = d0 + q / CPB;
+    const int d = (q0 + q) / CPB;
     const bool react = RECT || d > 0;  // the diagonal superblock pair sees every ordered pair already
     if (q > 0) {
       __syncthreads();  // every wave has stored its sums of chunk q-1
@@ -137,7 +157,8 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
     float hjx = 0.f, hjy = 0.f, hjz = 0.f;
     auto steps = [&](auto react_tag) {
       constexpr bool REACT = decltype(react_tag)::value;
-#pragma unroll 2
+      constexpr int kStepUnroll = R >= 16 ? 1 : 2;  // two steps in flight, registers permitting
+#pragma unroll kStepUnroll
       for (int k = 0; k < 64; k++) {
         const f2 sxj = {jx, jx}, syj = {jy, jy}, szj = {jz, jz}, smj = {jm, jm};
         // phases over the R/2 packed pairs: the dependent chain of one pair (r2 -> rsq -> g -> sums)
@@ -182,9 +203,15 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
     if ((q & 3) == 3 || q == nchunks - 1) {  // fold the fp32 sums of <= 256 sources into fp64
 #pragma unroll
       for (int r = 0; r < R / 2; r++) {
-        sx[2 * r] += (double)ax[r].x; sx[2 * r + 1] += (double)ax[r].y;
-        sy[2 * r] += (double)ay[r].x; sy[2 * r + 1] += (double)ay[r].y;
-        sz[2 * r] += (double)az[r].x; sz[2 * r + 1] += (double)az[r].y;
+        if constexpr (LACC) {
+          lacc[(0 * R + 2 * r) * kBlock + tid] += (double)ax[r].x; lacc[(0 * R + 2 * r + 1) * kBlock + tid] += (double)ax[r].y;
+          lacc[(1 * R + 2 * r) * kBlock + tid] += (double)ay[r].x; lacc[(1 * R + 2 * r + 1) * kBlock + tid] += (double)ay[r].y;
+          lacc[(2 * R + 2 * r) * kBlock + tid] += (double)az[r].x; lacc[(2 * R + 2 * r + 1) * kBlock + tid] += (double)az[r].y;
+        } else {
+          sx[2 * r] += (double)ax[r].x; sx[2 * r + 1] += (double)ax[r].y;
+          sy[2 * r] += (double)ay[r].x; sy[2 * r + 1] += (double)ay[r].y;
+          sz[2 * r] += (double)az[r].x; sz[2 * r + 1] += (double)az[r].y;
+        }
         ax[r] = ay[r] = az[r] = f2{0.f, 0.f};
       }
     }
@@ -195,9 +222,12 @@ __global__ __launch_bounds__(kBlock) void direct_sym_kernel(const float4* __rest
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int i = A * S + r * kBlock + tid;  // < NB * S: the accumulator is padded to that
-    unsafeAtomicAdd(&acc64[(size_t)i], sx[r] * (double)m0);
-    unsafeAtomicAdd(&acc64[plane_i + (size_t)i], sy[r] * (double)m0);
-    unsafeAtomicAdd(&acc64[2 * plane_i + (size_t)i], sz[r] * (double)m0);
+    const double fx = LACC ? lacc[(0 * R + r) * kBlock + tid] : sx[LACC ? 0 : r];
+    const double fy = LACC ? lacc[(1 * R + r) * kBlock + tid] : sy[LACC ? 0 : r];
+    const double fz = LACC ? lacc[(2 * R + r) * kBlock + tid] : sz[LACC ? 0 : r];
+    unsafeAtomicAdd(&acc64[(size_t)i], fx * (double)m0);
+    unsafeAtomicAdd(&acc64[plane_i + (size_t)i], fy * (double)m0);
+    unsafeAtomicAdd(&acc64[2 * plane_i + (size_t)i], fz * (double)m0);
   }
 }
 
@@ -276,7 +306,7 @@ static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, 
 // symmetric kernel worth it from here (measured, tools/sweep_sym_sizes.py): below, the one-sided kernel
 bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n) {
   if (ctx->tune_variant == 3) return true;
-  return ctx->tune_variant < 0 && n >= 20480;
+  return ctx->tune_variant < 0 && n >= 12288;
 }
 
 // bodies per lane R, measured (tools/sweep_sym_sizes.py, profiles/r01_sym_R_sweep.txt): the larger R,
@@ -287,7 +317,7 @@ static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
       ctx->tune_tpl == 16)
     return ctx->tune_tpl;
   if (two_sets) return n >= 49152 ? 16 : (n >= 16384 ? 8 : 4);
-  return n >= 786432 ? 16 : (n >= 98304 ? 8 : (n >= 30000 ? 4 : 2));
+  return n >= 786432 ? 16 : (n >= 28000 ? 8 : 4);
 }
 
 int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
@@ -298,11 +328,14 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
   const int S = kBlock * R;
   const int NB = (int)((n + S - 1) / S);
   const int D = NB / 2;
-  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * 16 + NB - 1) / NB;
-  if (splits > D + 1) splits = D + 1;
+  // workgroups = NB x splits; a split is a run of 64-body chunks of the flat (offset, chunk) list
+  const int total = (D + 1) * (S / 64);
+  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * kSymBlocksPerCU + NB - 1) / NB;
   if (splits < 1) splits = 1;
-  const int per = (D + 1 + splits - 1) / splits;
-  splits = (D + 1 + per - 1) / per;
+  int per = (total + splits - 1) / splits;
+  if (per < kSymMinChunks) per = kSymMinChunks;
+  if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);  // whole partners when there are enough
+  splits = (total + per - 1) / per;
   const size_t plane = (size_t)NB * S;
   const size_t acc_bytes = plane * 3 * sizeof(double);  // three component planes
   if (int rc = ctx->partial.reserve(acc_bytes)) return rc;
@@ -335,11 +368,13 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
   const int R = sym_R(ctx, ni < nj ? ni : nj, true);
   const int S = kBlock * R;
   const int NBI = (int)((ni + S - 1) / S), NBJ = (int)((nj + S - 1) / S);
-  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * 16 + NBI - 1) / NBI;
-  if (splits > NBJ) splits = NBJ;
+  const int total = NBJ * (S / 64);
+  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * kSymBlocksPerCU + NBI - 1) / NBI;
   if (splits < 1) splits = 1;
-  const int per = (NBJ + splits - 1) / splits;
-  splits = (NBJ + per - 1) / per;
+  int per = (total + splits - 1) / splits;
+  if (per < kSymMinChunks) per = kSymMinChunks;
+  if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);
+  splits = (total + per - 1) / per;
   const size_t plane_i = (size_t)NBI * S, plane_j = (size_t)NBJ * S;
   const size_t bi = plane_i * 3 * sizeof(double), bj = plane_j * 3 * sizeof(double);
   if (int rc = ctx->partial.reserve(bi + bj)) return rc;

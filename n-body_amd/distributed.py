@@ -42,6 +42,22 @@ class HipBackend:
     def __init__(self, ctx: Context):
         self.ctx = ctx
         self.device = ctx.torch_device
+        self._grid = self._tree = None
+
+    def close(self):
+        """Frees the lazily created grid / tree handles (also run at garbage collection)."""
+        lib = self.ctx._lib
+        if self._grid is not None and self.ctx.handle.value:
+            lib.nbody_hip_grid_destroy(self._grid)
+        if self._tree is not None and self.ctx.handle.value:
+            lib.nbody_hip_tree_destroy(self._tree)
+        self._grid = self._tree = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def drift(self, posm, vel, acc, dt):
         check(self.ctx._lib.nbody_hip_drift_packed(self.ctx.handle, posm.data_ptr(), vel.data_ptr(),

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nbody_amd as nb  # noqa: E402
 
+SPLITS = [int(x) for x in sys.argv[1:]] or [0]
 torch.cuda.set_device(0)
 ctx = nb.default_context(0)
 for n in (8192, 16384, 24576, 32768, 49152, 65536, 98304, 131072):
@@ -20,9 +21,9 @@ for n in (8192, 16384, 24576, 32768, 49152, 65536, 98304, 131072):
     ms = nb.time_direct_packed(ctx, p, p, 1.0, 1e-6, 5)
     line += f"  one-sided {ms:.3f} ms ({float(n) * n / ms / 1e9:.2f}e12)"
     for R in (2, 4, 8):
-        for splits in (0,):
+        for splits in SPLITS:
             ctx.tuning(3, R, splits)
             ms = nb.time_direct_packed(ctx, p, p, 1.0, 1e-6, 5)
-            line += f"  sym R={R} {ms:.3f} ms ({float(n) * n / ms / 1e9:.2f}e12)"
+            line += f"  R={R}/s{splits} {ms:.3f} ({float(n) * n / ms / 1e9:.2f})"
     print(line, flush=True)
 ctx.tuning()
