@@ -133,6 +133,7 @@ def _worker(rank, world, port, n, steps, out_dir, mode=None):
 
 
 @pytest.mark.parametrize("world,n,mode", [(2, 600, "pair"), (3, 601, "pair"), (4, 602, "pair"),
+                                          (8, 808, "pair"),  # the driver's largest run: 8 ranks
                                           (2, 600, "gather"), (3, 601, "gather")])
 def test_sharded_steps_match_single_process(tmp_path, world, n, mode, oracle, nb):
     from oracle_bind import host_state
