@@ -215,6 +215,7 @@ def other_roofline(a, nb, ps, torch):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if a.workload == "bh":
         tree = fc.getTree()
+        tree.countVisits(True)
         run = lambda: tree.computeForces(d, fc.theta_, fc.G_, fc.softening_eps_)  # noqa: E731
     else:
         grid = fc.getGrid()

@@ -165,6 +165,9 @@ NBODY_HIP_API int nbody_hip_update_positions(nbody_hip_ctx* ctx, nbody_particle_
 NBODY_HIP_API int nbody_hip_update_velocities(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt);
 /* ref: launchStoreAccelerationsKernel :144-152  a_old = a */
 NBODY_HIP_API int nbody_hip_store_accelerations(nbody_hip_ctx* ctx, nbody_particle_data* d);
+/* storeOldAccelerations + updatePositions in one pass (what Integrator::integrate does first,
+ * integrator.cu:224-231): a_old <- a ; x += v dt + a dt^2/2.  Same arithmetic, one launch instead of four. */
+NBODY_HIP_API int nbody_hip_drift(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt);
 /* ref: Integrator::integrate with a DirectForceCalculator :224-238, `steps` times:
  * one fused drift pass (a_old<-a, x update, float4 pack), the force kernel, and the
  * velocity update fused into the force reduction epilogue. */
@@ -261,6 +264,9 @@ typedef struct nbody_hip_tree nbody_hip_tree;
  * walk when there are few bodies, and the tree level at which the walk is divided; 0 = automatic.
  * Results are deterministic for a given setting; different settings differ by fp rounding only. */
 NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int split_level);
+/* Node-visit counting for nbody_hip_tree_stats (off by default: it costs a memset launch and an
+ * atomic per wave in every walk). */
+NBODY_HIP_API int nbody_hip_tree_count_visits(nbody_hip_tree* tree, int enable);
 
 /* ref: BarnesHutTree(max_particles) :204-210 */
 NBODY_HIP_API int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, nbody_hip_tree** out);

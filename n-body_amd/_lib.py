@@ -77,6 +77,7 @@ PROTOTYPES = {
     "nbody_hip_update_positions": (C.c_int, [_P, _PD, C.c_float]),
     "nbody_hip_update_velocities": (C.c_int, [_P, _PD, C.c_float]),
     "nbody_hip_store_accelerations": (C.c_int, [_P, _PD]),
+    "nbody_hip_drift": (C.c_int, [_P, _PD, C.c_float]),
     "nbody_hip_integrate_direct": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float, C.c_int]),
     "nbody_hip_drift_packed": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float]),
     "nbody_hip_kick_packed": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float]),
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "nbody_hip_tree_destroy": (C.c_int, [_P]),
     "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_tree_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
+    "nbody_hip_tree_count_visits": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_build": (C.c_int, [_P, _PD]),
     "nbody_hip_tree_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
     "nbody_hip_tree_build_packed": (C.c_int, [_P, _P, C.c_size_t]),

@@ -626,6 +626,10 @@ class BarnesHutTree:
     def tuning(self, replicas: int = 0, split_level: int = 0):
         check(self.ctx._lib.nbody_hip_tree_tuning(self._h, replicas, split_level))
 
+    def countVisits(self, enable: bool = True):
+        """stats()["nodes_visited"] is only maintained when enabled (it costs a launch per walk)."""
+        check(self.ctx._lib.nbody_hip_tree_count_visits(self._h, 1 if enable else 0))
+
     def build(self, d_particles: ParticleData):
         s = d_particles.struct()
         check(self.ctx._lib.nbody_hip_tree_build(self._h, C.byref(s)))
@@ -742,8 +746,8 @@ class Integrator:
             check(self.ctx._lib.nbody_hip_integrate_direct(
                 self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, 1))
             return
-        self.storeOldAccelerations(d_particles)
-        self.updatePositions(d_particles, dt)
+        s = d_particles.struct()  # a_old <- a and the position update in one pass
+        check(self.ctx._lib.nbody_hip_drift(self.ctx.handle, C.byref(s), dt))
         force_calc.computeForces(d_particles)
         self.updateVelocities(d_particles, dt)
 

@@ -476,6 +476,7 @@ struct nbody_hip_tree {
   unsigned long long* d_visits = nullptr;
   double* d_partial = nullptr;  // replicas x 3 x n fp64 partial sums (split traversal)
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
+  bool count_visits = false;
   size_t built_count = 0;
 };
 
@@ -584,13 +585,18 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
 }
 
 // the build proper, from packed bodies
-static int tree_build_packed(nbody_hip_tree* g, const float4* posm, size_t n) {
+// soa != nullptr: posm is a scratch array to be filled from the SoA bodies (fused with the bounding box)
+static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nbody_particle_data* soa = nullptr) {
   nbody_hip_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
 
-  if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+  if (soa) {
+    if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, g->d_enc)) return rc;
+  } else {
+    if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+  }
   hipLaunchKernelGGL(tree_root_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->d_root, g->d_level_base);
   hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_root,
                      g->d_keys_a, g->d_idx_a);
@@ -639,8 +645,7 @@ extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data
   NBH_HIP(hipSetDevice(ctx->device));
   if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
   float4* posm = static_cast<float4*>(ctx->posm.ptr);
-  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
-  return tree_build_packed(g, posm, n);
+  return tree_build_packed(g, posm, n, d);
 }
 
 extern "C" int nbody_hip_tree_build_packed(nbody_hip_tree* g, const nbody_float4* posm, size_t n) {
@@ -650,7 +655,7 @@ extern "C" int nbody_hip_tree_build_packed(nbody_hip_tree* g, const nbody_float4
   if (n > g->max_particles)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the tree's capacity %zu", n, g->max_particles);
   NBH_HIP(hipSetDevice(g->ctx->device));
-  return tree_build_packed(g, reinterpret_cast<const float4*>(posm), n);
+  return tree_build_packed(g, const_cast<float4*>(reinterpret_cast<const float4*>(posm)), n);
 }
 
 // walk of the sorted bodies [first, first + count); output SoA (ax, ay, az) or float4 (acc4), at
@@ -664,7 +669,8 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   const int n = count;
   const int blocks = (n + kBlock - 1) / kBlock;
   const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
-  NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), ctx->stream));
+  unsigned long long* visits = g->count_visits ? g->d_visits : nullptr;
+  if (visits) NBH_HIP(hipMemsetAsync(visits, 0, sizeof(unsigned long long), ctx->stream));
   if (n == 0) return NBODY_HIP_OK;
   // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
   int K = 1;
@@ -680,7 +686,7 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   const bool guard = eps2 < 1e-12f;
 #define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
-                     g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, g->d_visits,               \
+                     g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,                     \
                      g->d_level_base, split_level, g->d_partial)
   if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
@@ -714,6 +720,16 @@ extern "C" int nbody_hip_tree_compute_forces_packed(nbody_hip_tree* g, size_t fi
                     first_sorted + count, g->built_count);
   return tree_walk(g, (int)first_sorted, (int)count, theta, G, eps, nullptr, nullptr, nullptr,
                    reinterpret_cast<float4*>(acc_out));
+}
+
+extern "C" int nbody_hip_tree_count_visits(nbody_hip_tree* g, int enable) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  g->count_visits = enable != 0;
+  if (!g->count_visits) {
+    NBH_HIP(hipSetDevice(g->ctx->device));
+    NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), g->ctx->stream));
+  }
+  return NBODY_HIP_OK;
 }
 
 // experiments: replicas / split level of the split traversal (0 = automatic)

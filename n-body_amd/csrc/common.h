@@ -81,6 +81,12 @@ struct nbody_hip_ctx {
 
 namespace nbh {
 
+// v + (a_old + a) dt/2 as one explicit chain (add, then fma): integrator.cu:33-35 under nvcc's default
+// contraction; shared by every kick (SoA, float4, fused into the force finalize) so they round alike
+__device__ __forceinline__ float kick1(float v, float a_old, float a_new, float dt_half) {
+  return __builtin_fmaf(a_old + a_new, dt_half, v);
+}
+
 // direct.hip
 int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
                   const float4* sources, size_t n_sources, float G, float eps2,
@@ -104,6 +110,8 @@ int pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z
 // spatial_hash.hip: order-preserving-integer bounding box of packed bodies into enc[6]
 // (min x,y,z then max x,y,z); decode with ordered_to_float on the device.
 int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc);
+int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
+                     float4* posm, unsigned int* enc);
 
 __device__ __forceinline__ unsigned int float_to_ordered(float f) {
   const unsigned int u = __float_as_uint(f);

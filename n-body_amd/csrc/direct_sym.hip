@@ -276,9 +276,9 @@ __global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
   } else {
     ax[i] = fx; ay[i] = fy; az[i] = fz;
     if (vx) {
-      vx[i] += (aox[i] + fx) * half_dt;
-      vy[i] += (aoy[i] + fy) * half_dt;
-      vz[i] += (aoz[i] + fz) * half_dt;
+      vx[i] = kick1(vx[i], aox[i], fx, half_dt);
+      vy[i] = kick1(vy[i], aoy[i], fy, half_dt);
+      vz[i] = kick1(vz[i], aoz[i], fz, half_dt);
     }
   }
 }

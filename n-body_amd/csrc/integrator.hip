@@ -27,6 +27,13 @@ static inline int stream_blocks(size_t items) {
 struct Soa3 { float* x; float* y; float* z; };
 struct CSoa3 { const float* x; const float* y; const float* z; };
 
+// x + (v dt + a dt^2/2), written out as ONE explicit chain -- v*dt, then fma(a, h, .), then the add: the
+// contraction nvcc's default -fmad makes of integrator.cu:16-19 -- so that the SoA, fused and float4
+// drift kernels round identically (a sharded run then reproduces the single-GPU one bit for bit).
+__device__ __forceinline__ float drift1(float p, float v, float a, float dt, float h) {
+  return p + __builtin_fmaf(a, h, v * dt);
+}
+
 // x += v*dt + a*(0.5*dt*dt)     (integrator.cu:16-19; same operation order)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void update_positions_kernel(Soa3 p, CSoa3 v, CSoa3 a,
@@ -41,10 +48,10 @@ __global__ __launch_bounds__(kBlock) void update_positions_kernel(Soa3 p, CSoa3 
     float4 pp = reinterpret_cast<float4*>(p.c)[i];                             \
     const float4 vv = reinterpret_cast<const float4*>(v.c)[i];                 \
     const float4 aa = reinterpret_cast<const float4*>(a.c)[i];                 \
-    pp.x += vv.x * dt + aa.x * dt2_half;                                       \
-    pp.y += vv.y * dt + aa.y * dt2_half;                                       \
-    pp.z += vv.z * dt + aa.z * dt2_half;                                       \
-    pp.w += vv.w * dt + aa.w * dt2_half;                                       \
+    pp.x = drift1(pp.x, vv.x, aa.x, dt, dt2_half);                             \
+    pp.y = drift1(pp.y, vv.y, aa.y, dt, dt2_half);                             \
+    pp.z = drift1(pp.z, vv.z, aa.z, dt, dt2_half);                             \
+    pp.w = drift1(pp.w, vv.w, aa.w, dt, dt2_half);                             \
     reinterpret_cast<float4*>(p.c)[i] = pp;                                    \
   }
       NBH_POS_AXIS(x) NBH_POS_AXIS(y) NBH_POS_AXIS(z)
@@ -53,15 +60,15 @@ __global__ __launch_bounds__(kBlock) void update_positions_kernel(Soa3 p, CSoa3 
     // tail
     const size_t i = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
-      p.x[i] += v.x[i] * dt + a.x[i] * dt2_half;
-      p.y[i] += v.y[i] * dt + a.y[i] * dt2_half;
-      p.z[i] += v.z[i] * dt + a.z[i] * dt2_half;
+      p.x[i] = drift1(p.x[i], v.x[i], a.x[i], dt, dt2_half);
+      p.y[i] = drift1(p.y[i], v.y[i], a.y[i], dt, dt2_half);
+      p.z[i] = drift1(p.z[i], v.z[i], a.z[i], dt, dt2_half);
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-      p.x[i] += v.x[i] * dt + a.x[i] * dt2_half;
-      p.y[i] += v.y[i] * dt + a.y[i] * dt2_half;
-      p.z[i] += v.z[i] * dt + a.z[i] * dt2_half;
+      p.x[i] = drift1(p.x[i], v.x[i], a.x[i], dt, dt2_half);
+      p.y[i] = drift1(p.y[i], v.y[i], a.y[i], dt, dt2_half);
+      p.z[i] = drift1(p.z[i], v.z[i], a.z[i], dt, dt2_half);
     }
   }
 }
@@ -80,10 +87,10 @@ __global__ __launch_bounds__(kBlock) void update_velocities_kernel(Soa3 v, CSoa3
     float4 vv = reinterpret_cast<float4*>(v.c)[i];                             \
     const float4 o = reinterpret_cast<const float4*>(ao.c)[i];                 \
     const float4 w = reinterpret_cast<const float4*>(an.c)[i];                 \
-    vv.x += (o.x + w.x) * dt_half;                                             \
-    vv.y += (o.y + w.y) * dt_half;                                             \
-    vv.z += (o.z + w.z) * dt_half;                                             \
-    vv.w += (o.w + w.w) * dt_half;                                             \
+    vv.x = kick1(vv.x, o.x, w.x, dt_half);                                     \
+    vv.y = kick1(vv.y, o.y, w.y, dt_half);                                     \
+    vv.z = kick1(vv.z, o.z, w.z, dt_half);                                     \
+    vv.w = kick1(vv.w, o.w, w.w, dt_half);                                     \
     reinterpret_cast<float4*>(v.c)[i] = vv;                                    \
   }
       NBH_VEL_AXIS(x) NBH_VEL_AXIS(y) NBH_VEL_AXIS(z)
@@ -91,15 +98,15 @@ __global__ __launch_bounds__(kBlock) void update_velocities_kernel(Soa3 v, CSoa3
     }
     const size_t i = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
-      v.x[i] += (ao.x[i] + an.x[i]) * dt_half;
-      v.y[i] += (ao.y[i] + an.y[i]) * dt_half;
-      v.z[i] += (ao.z[i] + an.z[i]) * dt_half;
+      v.x[i] = kick1(v.x[i], ao.x[i], an.x[i], dt_half);
+      v.y[i] = kick1(v.y[i], ao.y[i], an.y[i], dt_half);
+      v.z[i] = kick1(v.z[i], ao.z[i], an.z[i], dt_half);
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-      v.x[i] += (ao.x[i] + an.x[i]) * dt_half;
-      v.y[i] += (ao.y[i] + an.y[i]) * dt_half;
-      v.z[i] += (ao.z[i] + an.z[i]) * dt_half;
+      v.x[i] = kick1(v.x[i], ao.x[i], an.x[i], dt_half);
+      v.y[i] = kick1(v.y[i], ao.y[i], an.y[i], dt_half);
+      v.z[i] = kick1(v.z[i], ao.z[i], an.z[i], dt_half);
     }
   }
 }
@@ -115,11 +122,11 @@ __global__ __launch_bounds__(kBlock) void drift_pack_kernel(Soa3 p, CSoa3 v, CSo
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     const float ax = a.x[i], ay = a.y[i], az = a.z[i];
     ao.x[i] = ax; ao.y[i] = ay; ao.z[i] = az;
-    const float x = p.x[i] + (v.x[i] * dt + ax * dt2_half);
-    const float y = p.y[i] + (v.y[i] * dt + ay * dt2_half);
-    const float z = p.z[i] + (v.z[i] * dt + az * dt2_half);
+    const float x = drift1(p.x[i], v.x[i], ax, dt, dt2_half);
+    const float y = drift1(p.y[i], v.y[i], ay, dt, dt2_half);
+    const float z = drift1(p.z[i], v.z[i], az, dt, dt2_half);
     p.x[i] = x; p.y[i] = y; p.z[i] = z;
-    posm[i] = make_float4(x, y, z, m[i]);
+    if (posm) posm[i] = make_float4(x, y, z, m[i]);
   }
 }
 
@@ -136,9 +143,9 @@ __global__ __launch_bounds__(kBlock) void drift_packed_kernel(float4* __restrict
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     float4 p = posm[i];
     const float4 v = vel[i], a = acc[i];
-    p.x += v.x * dt + a.x * dt2_half;
-    p.y += v.y * dt + a.y * dt2_half;
-    p.z += v.z * dt + a.z * dt2_half;
+    p.x = drift1(p.x, v.x, a.x, dt, dt2_half);
+    p.y = drift1(p.y, v.y, a.y, dt, dt2_half);
+    p.z = drift1(p.z, v.z, a.z, dt, dt2_half);
     posm[i] = p;
   }
 }
@@ -152,9 +159,9 @@ __global__ __launch_bounds__(kBlock) void kick_packed_kernel(float4* __restrict_
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     float4 v = vel[i];
     const float4 o = acc_old[i], w = acc_new[i];
-    v.x += (o.x + w.x) * dt_half;
-    v.y += (o.y + w.y) * dt_half;
-    v.z += (o.z + w.z) * dt_half;
+    v.x = kick1(v.x, o.x, w.x, dt_half);
+    v.y = kick1(v.y, o.y, w.y, dt_half);
+    v.z = kick1(v.z, o.z, w.z, dt_half);
     vel[i] = v;
   }
 }
@@ -228,6 +235,23 @@ extern "C" int nbody_hip_store_accelerations(nbody_hip_ctx* ctx, nbody_particle_
   NBH_HIP(hipMemcpyAsync(d->acc_old_x, d->acc_x, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   NBH_HIP(hipMemcpyAsync(d->acc_old_y, d->acc_y, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   NBH_HIP(hipMemcpyAsync(d->acc_old_z, d->acc_z, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return NBODY_HIP_OK;
+}
+
+// a_old <- a and x += v dt + a dt^2/2 in ONE pass (the reference's storeAccelerations + updatePositions
+// pair, integrator.cu:224-231): for the steps whose force evaluation is not the fused direct one
+extern "C" int nbody_hip_drift(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt) {
+  if (int rc = check_pd(ctx, d)) return rc;
+  const size_t n = d->count;
+  if (n == 0) return NBODY_HIP_OK;
+  if (!d->acc_old_x || !d->acc_old_y || !d->acc_old_z)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null acc_old arrays");
+  NBH_HIP(hipSetDevice(ctx->device));
+  Soa3 p{d->pos_x, d->pos_y, d->pos_z}, ao{d->acc_old_x, d->acc_old_y, d->acc_old_z};
+  CSoa3 v{d->vel_x, d->vel_y, d->vel_z}, a{d->acc_x, d->acc_y, d->acc_z};
+  hipLaunchKernelGGL(drift_pack_kernel, dim3(stream_blocks(n)), dim3(kBlock), 0, ctx->stream, p, v, a, ao,
+                     d->mass, static_cast<float4*>(nullptr), n, dt);
+  NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
 

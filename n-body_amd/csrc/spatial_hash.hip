@@ -81,6 +81,54 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
   }
 }
 
+// SoA -> float4 packing and the bounding box in ONE pass (the build's first two kernels fused):
+// <= 256 workgroups stride over the bodies, write posm and keep the running min/max
+__global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, const float* __restrict__ m,
+                                                           int n, float4* __restrict__ posm,
+                                                           unsigned int* __restrict__ enc) {
+  __shared__ float red[4][6];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = make_float4(x[i], y[i], z[i], m[i]);
+    posm[i] = p;
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int k = 1; k < 4; k++) v = a < 3 ? fminf(v, red[k][a]) : fmaxf(v, red[k][a]);
+    if (a < 3) atomicMin(&enc[a], float_to_ordered(v));
+    else atomicMax(&enc[a], float_to_ordered(v));
+  }
+}
+
+int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
+                     float4* posm, unsigned int* enc) {
+  const int blocks = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
+  hipLaunchKernelGGL(pack_bbox_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream, x, y, z, m,
+                     n, posm, enc);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
 int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc) {
   const int blocks = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
@@ -419,7 +467,9 @@ static int bits_for(long long total) {
 // bounds == nullptr: bounding box of the bodies padded by 0.001 (the reference's build);
 // otherwise {lo x,y,z, hi x,y,z} is used as the (already padded) box -- the sharded path passes
 // the GLOBAL box so that every rank bins on the same grid.
-static int grid_build_packed(nbody_hip_grid* g, const float4* posm, size_t n, const float* bounds) {
+// soa != nullptr: posm is a scratch array to be filled from the SoA bodies (fused with the bounding box)
+static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const float* bounds,
+                             const nbody_particle_data* soa = nullptr) {
   nbody_hip_ctx* ctx = g->ctx;
   // the grid dimensions come back to the host every build (they size the force launch)
   NBH_NOT_CAPTURABLE(ctx, "the spatial-hash grid build");
@@ -444,7 +494,11 @@ static int grid_build_packed(nbody_hip_grid* g, const float4* posm, size_t n, co
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
     NBH_HIP(hipMemcpyAsync(g->d_info, g->h_info, sizeof(GridInfo), hipMemcpyHostToDevice, st));
   } else {
-    if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+    if (soa) {
+      if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, g->d_enc)) return rc;
+    } else {
+      if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+    }
     hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info);
     NBH_LAUNCH_CHECK();
     // the one host round trip of the build: the grid size decides validity (and, for the
@@ -483,8 +537,7 @@ extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data
   NBH_HIP(hipSetDevice(ctx->device));
   if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
   float4* posm = static_cast<float4*>(ctx->posm.ptr);
-  if (int rc = pack_posm(ctx, d->pos_x, d->pos_y, d->pos_z, d->mass, n, posm)) return rc;
-  return grid_build_packed(g, posm, n, nullptr);
+  return grid_build_packed(g, posm, n, nullptr, d);
 }
 
 extern "C" int nbody_hip_grid_build_packed(nbody_hip_grid* g, const nbody_float4* posm, size_t n,
@@ -499,7 +552,7 @@ extern "C" int nbody_hip_grid_build_packed(nbody_hip_grid* g, const nbody_float4
       if (!(bounds[3 + a] >= bounds[a]) || !(bounds[3 + a] - bounds[a] < INFINITY))
         return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "invalid grid bounds");
   NBH_HIP(hipSetDevice(g->ctx->device));
-  return grid_build_packed(g, reinterpret_cast<const float4*>(posm), n, bounds);
+  return grid_build_packed(g, const_cast<float4*>(reinterpret_cast<const float4*>(posm)), n, bounds);
 }
 
 static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float eps, float* ax,

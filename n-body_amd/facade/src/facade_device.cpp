@@ -304,8 +304,7 @@ void Integrator::integrate(ParticleData* d, ForceCalculator* fc, float dt) {
     NBODY_CHECK(nbody_hip_integrate_direct(facadeContext(), raw(d), fc->getGravitationalConstant(), eps * eps, dt, 1));
     return;
   }
-  storeOldAccelerations(d);
-  updatePositions(d, dt);
+  NBODY_CHECK(nbody_hip_drift(facadeContext(), raw(d), dt));  // storeOldAccelerations + updatePositions, one pass
   fc->computeForces(d);
   updateVelocities(d, dt);
 }

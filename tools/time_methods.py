@@ -38,6 +38,8 @@ def main():
                 tree.setParams(10, leaf_max)
                 tb = timeit(lambda: tree.build(d))
                 tf = timeit(lambda: tree.computeForces(d, 0.5, 1.0, 0.1))
+                tree.countVisits(True)
+                tree.computeForces(d, 0.5, 1.0, 0.1)
                 st = tree.stats()
                 waves = (n + 63) // 64
                 print(f"BH {name} N={n} leaf_max={leaf_max}: build {tb:.2f} ms, traverse {tf:.2f} ms, "
