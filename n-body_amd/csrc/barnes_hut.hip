@@ -28,6 +28,7 @@
 // Roofline: build = HBM streaming + sort (~100 B/body); traversal = latency/L2 bound:
 // 32 B per node visited per WAVE (not per body).
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -280,6 +281,84 @@ __global__ __launch_bounds__(kTopBlock) void top_monopole_kernel(int top_level,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Monopoles without the level-by-level dependency, for small trees (n <= kPrefixMax): a node covers a
+// contiguous range of the Morton-sorted bodies, so its {sum m, sum m r} is a difference of two
+// entries of the fp64 prefix sums over the sorted bodies.  Two launches instead of eleven dependent
+// passes (57 -> 12 us at 10,000 bodies).  The subtraction loses |prefix| / |node| of fp64's 1e-16:
+// invisible after rounding to the fp32 traversal record; one-body leaves are copied, not subtracted.
+// Deterministic (fixed summation tree).  Large trees keep the bottom-up passes, whose cost is
+// bandwidth, not latency, and whose sums are exact to fp64 at every level.
+// ---------------------------------------------------------------------------------------
+constexpr int kPrefixMax = 16384;
+constexpr int kPrefixBlock = 1024;
+
+__global__ __launch_bounds__(kPrefixBlock) void prefix_bodies_kernel(const float4* __restrict__ sorted, int n,
+                                                                     double4* __restrict__ P) {
+  __shared__ double tot[4][kPrefixBlock];
+  const int tid = threadIdx.x;
+  const int C = (n + kPrefixBlock - 1) / kPrefixBlock;  // consecutive bodies per thread
+  const int k0 = min(n, tid * C), k1 = min(n, k0 + C);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = k0; k < k1; k++) {
+    const float4 p = sorted[k];
+    const double mb = (double)p.w;
+    s[0] += mb * (double)p.x; s[1] += mb * (double)p.y; s[2] += mb * (double)p.z; s[3] += mb;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) tot[c][tid] = s[c];
+  __syncthreads();
+  for (int off = 1; off < kPrefixBlock; off <<= 1) {  // inclusive scan of the per-thread totals
+    double v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[c] = tid >= off ? tot[c][tid - off] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) tot[c][tid] += v[c];
+    __syncthreads();
+  }
+  double run[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) run[c] = tid > 0 ? tot[c][tid - 1] : 0.0;
+  for (int k = k0; k < k1; k++) {  // P[k] = sums over the bodies before k
+    P[k] = make_double4(run[0], run[1], run[2], run[3]);
+    const float4 p = sorted[k];
+    const double mb = (double)p.w;
+    run[0] += mb * (double)p.x; run[1] += mb * (double)p.y; run[2] += mb * (double)p.z; run[3] += mb;
+  }
+  if (k0 < k1 && k1 == n) P[n] = make_double4(run[0], run[1], run[2], run[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __restrict__ level_base, int max_depth,
+                                                                 const float4* __restrict__ sorted,
+                                                                 const double4* __restrict__ P,
+                                                                 const TreeRoot* __restrict__ root, TreeArrays t) {
+  const int nid = blockIdx.x * kBlock + threadIdx.x;
+  if (nid >= level_base[max_depth + 1]) return;
+  int level = 0;
+  while (level < max_depth && nid >= level_base[level + 1]) level++;
+  const int first = t.first[nid], last = t.last[nid], cnt = last - first;
+  const int c0 = t.child0[nid];
+  double4 mono;
+  if (cnt == 1) {
+    const float4 p = sorted[first];
+    mono = make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
+  } else {
+    const double4 a = P[first], b = P[last];
+    const double ms = b.w - a.w;
+    mono = ms > 0.0 ? make_double4((b.x - a.x) / ms, (b.y - a.y) / ms, (b.z - a.z) / ms, ms)
+                    : make_double4(0.0, 0.0, 0.0, 0.0);
+  }
+  const float h = ldexpf(root->half, -level);
+  const float size = 2.0f * h;  // :168
+  NodeRec r;
+  r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
+  r.size2 = size * size;
+  r.first = first; r.count = cnt;
+  r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
+  t.rec[nid] = r;
+}
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // |d|^2 of the walk: dx*dx, then two fused multiply-adds -- the chain nvcc's default contraction makes
@@ -475,6 +554,7 @@ struct nbody_hip_tree {
   size_t tmp_bytes = 0;
   unsigned long long* d_visits = nullptr;
   double* d_partial = nullptr;  // replicas x 3 x n fp64 partial sums (split traversal)
+  double4* d_prefix = nullptr;  // kPrefixMax + 1 prefix sums of the sorted bodies (small trees)
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
   bool count_visits = false;
   size_t built_count = 0;
@@ -485,7 +565,7 @@ static void tree_release(nbody_hip_tree* g) {
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                   g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m,
-                  g->d_tmp, g->d_visits, g->d_partial};
+                  g->d_tmp, g->d_visits, g->d_partial, g->d_prefix};
   for (void* p : ptrs) (void)hipFree(p);
   delete g;
 }
@@ -540,6 +620,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
   if (e == hipSuccess) e = dmalloc(&g->d_visits, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
+  if (e == hipSuccess) e = dmalloc(&g->d_prefix, (size_t)kPrefixMax + 1);
   if (e == hipSuccess) {
     size_t t1 = 0, t2 = 0;
     e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n, 0,
@@ -618,14 +699,23 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
                      g->d_keys_b, ni, g->max_depth, g->leaf_max, g->d_flag, g->d_incl, g->t, g->capacity,
                      g->d_level_base);
   NBH_LAUNCH_CHECK();
-  // monopoles bottom-up: wide levels one launch each, the narrow top (all levels when the whole
-  // tree is small) in a single workgroup
-  const int top = n <= 16384 ? g->max_depth : (g->max_depth < 4 ? g->max_depth : 4);
-  for (int L = g->max_depth; L > top; L--)
-    hipLaunchKernelGGL(level_monopole_kernel, dim3(1024), dim3(kBlock), 0, st, L, g->d_level_base,
-                       g->d_sorted, g->d_root, g->t);
-  hipLaunchKernelGGL(top_monopole_kernel, dim3(1), dim3(kTopBlock), 0, st, top, g->d_level_base, g->d_sorted,
-                     g->d_root, g->t);
+  if (ni <= kPrefixMax) {
+    // small tree: every node's monopole from the prefix sums of the sorted bodies (see above)
+    hipLaunchKernelGGL(prefix_bodies_kernel, dim3(1), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix);
+    // the node count is only known on the device: one thread per possible node of a tree of ni bodies
+    const size_t node_bound = std::min((size_t)g->capacity,
+                                       n + (size_t)levels * (n / (size_t)(g->leaf_max + 1) + 1) + 16);
+    hipLaunchKernelGGL(prefix_monopole_kernel, dim3((unsigned)((node_bound + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, g->d_level_base, g->max_depth, g->d_sorted, g->d_prefix, g->d_root, g->t);
+  } else {
+    // monopoles bottom-up: wide levels one launch each, the narrow top in a single workgroup
+    const int top = g->max_depth < 4 ? g->max_depth : 4;
+    for (int L = g->max_depth; L > top; L--)
+      hipLaunchKernelGGL(level_monopole_kernel, dim3(1024), dim3(kBlock), 0, st, L, g->d_level_base,
+                         g->d_sorted, g->d_root, g->t);
+    hipLaunchKernelGGL(top_monopole_kernel, dim3(1), dim3(kTopBlock), 0, st, top, g->d_level_base, g->d_sorted,
+                       g->d_root, g->t);
+  }
   NBH_LAUNCH_CHECK();
   g->built_count = n;
   return NBODY_HIP_OK;
