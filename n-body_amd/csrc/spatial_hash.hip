@@ -44,20 +44,9 @@ __global__ void bbox_init_kernel(unsigned int* enc) {
   else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;           // maxs
 }
 
-// min/max of x,y,z: wave64 shuffle reduce -> LDS across the block's 4 waves -> 6 atomics per
-// BLOCK on order-preserving integers, from at most 256 blocks (1,536 atomics in all: every wave
-// hitting the same six words serialises at ~11 ns each, measured 282 us with 24,576 of them).
-// The reference CAS-loops float atomics from every block (force_barnes_hut.cu:41-110).
-__global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__ posm, int n,
-                                                      unsigned int* __restrict__ enc) {
-  __shared__ float red[4][6];
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 p = posm[i];
-    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
-  }
+// per-thread min/max -> wave64 shuffle reduce -> LDS across the block's 4 waves -> 6 atomics per block
+__device__ __forceinline__ void block_bbox_commit(float (&lo)[3], float (&hi)[3], float (&red)[4][6],
+                                                  unsigned int* __restrict__ enc) {
 #pragma unroll
   for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -81,6 +70,23 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
   }
 }
 
+// min/max of x,y,z: wave64 shuffle reduce -> LDS across the block's 4 waves -> 6 atomics per
+// BLOCK on order-preserving integers, from at most 256 blocks (1,536 atomics in all: every wave
+// hitting the same six words serialises at ~11 ns each, measured 282 us with 24,576 of them).
+// The reference CAS-loops float atomics from every block (force_barnes_hut.cu:41-110).
+__global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__ posm, int n,
+                                                      unsigned int* __restrict__ enc) {
+  __shared__ float red[4][6];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = posm[i];
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+  block_bbox_commit(lo, hi, red, enc);
+}
+
 // SoA -> float4 packing and the bounding box in ONE pass (the build's first two kernels fused):
 // <= 256 workgroups stride over the bodies, write posm and keep the running min/max
 __global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -96,27 +102,7 @@ __global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restri
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
     lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
-      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
-    }
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int a = threadIdx.x;
-    float v = red[0][a];
-    for (int k = 1; k < 4; k++) v = a < 3 ? fminf(v, red[k][a]) : fmaxf(v, red[k][a]);
-    if (a < 3) atomicMin(&enc[a], float_to_ordered(v));
-    else atomicMax(&enc[a], float_to_ordered(v));
-  }
+  block_bbox_commit(lo, hi, red, enc);
 }
 
 int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
