@@ -317,3 +317,19 @@ def test_range_walks_equal_whole_walk(nb, ctx, n, parts):
         check(lib.nbody_hip_tree_compute_forces_packed(h, n, 0, 0.5, 1.0, 0.05, out.data_ptr()))  # empty range: no-op
     finally:
         lib.nbody_hip_tree_destroy(h)
+
+
+# BASELINE config 4 in small, against the committed golden vectors (tests/golden/make_golden.py)
+def test_golden_two_galaxies_2048(nb, ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twogalaxies2048_barnes_hut.npz"))
+    ic = {k: g[k] for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
+    d, _ = to_device(nb, ic)
+    calc = nb.BarnesHutCalculator(float(g["theta"]))
+    calc.setGravitationalConstant(float(g["G"]))
+    calc.setSofteningParameter(float(g["eps"]))
+    calc.computeForces(d)
+    assert rel_err(acc_of(d), g["acc"]).max() < TOL
+    st = calc.getTree().stats()
+    assert st["node_count"] == int(g["node_count"])
+    assert abs(st["root_mass"] - float(g["root_mass"])) < 1e-6 * float(g["root_mass"])

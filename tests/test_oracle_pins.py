@@ -2,6 +2,7 @@
 tests and examples hold for the hot path.  Values only -- the reference's
 test sources are not copied.  CPU-only."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -194,3 +195,34 @@ def test_barnes_hut_contract(oracle, nb):
             errs[theta] = float(np.max(np.abs(bmag - dmag) / np.maximum(dmag, 1e-12)))
         assert errs[0.1] < 0.10
         assert errs[0.3] <= 1.1 * errs[0.8] + 1e-12
+
+
+# ---- the committed golden fixtures of the two approximate methods: the oracle must keep producing them
+# (tests/golden/make_golden.py; the GPU twins are in test_barnes_hut_gpu.py / test_spatial_hash_gpu.py)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_reproduces_barnes_hut_golden(oracle):
+    g = np.load(os.path.join(GOLDEN, "twogalaxies2048_barnes_hut.npz"))
+    n = g["pos_x"].size
+    eps2 = float(np.float32(g["eps"]) * np.float32(g["eps"]))
+    bx, by, bz, root_mass, nodes = oracle.barnes_hut_forces(g["pos_x"], g["pos_y"], g["pos_z"], g["mass"],
+                                                            np.arange(n), float(g["G"]), eps2, float(g["theta"]))
+    assert nodes == int(g["node_count"]) and root_mass == float(g["root_mass"])
+    assert np.array_equal(np.stack([bx, by, bz], 1), g["acc"])
+    # theta = 0.5: a few per cent of the exact sum at worst (docs/architecture/algorithms.md:450-454 "~1 %")
+    err = np.linalg.norm(g["acc"] - g["acc_direct"], axis=1) / np.linalg.norm(g["acc_direct"], axis=1)
+    assert np.median(err) < 0.01 and np.quantile(err, 0.99) < 0.06 and err.max() < 0.25
+
+
+def test_oracle_reproduces_spatial_hash_golden(oracle):
+    g = np.load(os.path.join(GOLDEN, "uniform4096_spatial_hash.npz"))
+    eps2 = float(np.float32(g["eps"]) * np.float32(g["eps"]))
+    for name, cutoff in (("acc_c1", 1.0), ("acc_c2", 2.0)):
+        a = np.stack(oracle.spatial_hash_forces(g["pos_x"], g["pos_y"], g["pos_z"], g["mass"], float(g["G"]), eps2,
+                                                float(g["cell"]), cutoff), 1)
+        assert np.array_equal(a, g[name]), name
+    # cutoff <= cell: the 27-cell search finds every pair within the cutoff
+    assert np.allclose(g["acc_c1"], g["acc_cutoff_direct"], rtol=1e-5, atol=1e-6)
+    lo, hi, dims = oracle.hash_grid(g["pos_x"], g["pos_y"], g["pos_z"], float(g["cell"]))
+    assert list(dims) == list(g["dims"])

@@ -234,3 +234,22 @@ def test_full_size_uniform_box(nb, oracle, ctx):
     assert rel_err(a[idx], dc).max() < TOL
     # short-range forces of a uniform medium cancel on average: the mean is far below the rms
     assert np.abs(a.mean(0)).max() < 0.02 * a.std(0).min()
+
+
+# BASELINE config 5 in small, against the committed golden vectors (tests/golden/make_golden.py)
+def test_golden_uniform_4096(nb, ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "uniform4096_spatial_hash.npz"))
+    ic = {k: g[k] for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
+    d, _ = to_device(nb, ic)
+    for name, cutoff in (("acc_c1", 1.0), ("acc_c2", 2.0)):
+        calc = nb.SpatialHashCalculator(float(g["cell"]), cutoff)
+        calc.setGravitationalConstant(float(g["G"]))
+        calc.setSofteningParameter(float(g["eps"]))
+        calc.computeForces(d)
+        ref = g[name].astype(np.float64)
+        scale = np.sqrt((ref ** 2).sum(1).mean())
+        assert np.abs(acc_of(d) - ref).max() < 1e-5 * max(scale, np.abs(ref).max() * 0.1), name
+        assert list(calc.getGrid().getGridDims()) == list(g["dims"])
+    cs, ce, pc, si = calc.getGrid().copyCellDataToHost()
+    assert np.array_equal(pc, g["cell_of"])   # every body in the cell the oracle puts it in
