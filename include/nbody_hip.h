@@ -261,9 +261,10 @@ NBODY_HIP_API int nbody_hip_cell_z_packed(nbody_hip_ctx* ctx, const nbody_float4
 typedef struct nbody_hip_tree nbody_hip_tree;
 
 /* Tuning hook for measurements: number of replicas (power of two, <= 16) that share each wave's
- * walk when there are few bodies, and the tree level at which the walk is divided; 0 = automatic.
+ * walk when there are few bodies, and the number of ownership units per replica (a unit is a subtree
+ * of at most n / (units K) bodies; default: n / 96 whatever K); 0 = automatic.
  * Results are deterministic for a given setting; different settings differ by fp rounding only. */
-NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int split_level);
+NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int units_per_replica);
 /* Node-visit counting for nbody_hip_tree_stats (off by default: it costs a memset launch and an
  * atomic per wave in every walk). */
 NBODY_HIP_API int nbody_hip_tree_count_visits(nbody_hip_tree* tree, int enable);

@@ -44,7 +44,8 @@ namespace nbh {
 
 constexpr int kMaxDepth = 10;      // 30-bit Morton keys
 constexpr int kStack = 8 * (kMaxDepth + 2);
-constexpr int kSplitBudget = 262144;  // replicas * n of the split traversal (= 4096 waves)
+constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
+constexpr int kSplitAuto = 262144;     // automatic choice: replicas * n up to here (= 4096 waves)
 constexpr int kMaxReplicas = 16;
 
 struct TreeRoot {
@@ -375,26 +376,26 @@ __device__ __forceinline__ float bh_dist2(float dx, float dy, float dz) {
 //
 // SPLIT (few bodies): a walk is a chain of dependent node fetches, so its speed comes from having
 // many waves in flight -- with n / 64 waves below a few thousand the chip idles.  gridDim.y = K
-// replicas then share each wave's walk: nodes of the levels <= split level (ids < split_end,
-// "shared zone") are visited by every replica, but a node there contributes, and is descended
-// below the split level, only in the replica that owns it (id mod K); deeper nodes belong to the
-// replica that entered their subtree.  The replicas' fp64 partial sums are added in replica order
-// by bh_combine_kernel (deterministic).
+// replicas then share each wave's walk.  Nodes holding more than `unit_max` bodies form the "shared
+// zone": every replica visits them, but such a node contributes only in the replica that owns it
+// (id mod K).  A child of a shared node with at most unit_max bodies is a UNIT: only its owner
+// enters it, and everything below belongs to that replica.  Units are bounded in size (n / 96
+// bodies by default), so the replicas' loads are balanced whatever the mass distribution (a split
+// at a fixed tree level left the replica owning a dense core with most of the work).  The
+// replicas' fp64 partial sums are added in replica order by bh_combine_kernel (deterministic).
 // ---------------------------------------------------------------------------------------
 template <bool GUARD, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
     const int* __restrict__ idx, int t_first, int n, float theta2, float eps2, float G,
     float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4,
-    unsigned long long* __restrict__ visit_count, const int* __restrict__ level_base, int split_level,
-    double* __restrict__ partial) {
+    unsigned long long* __restrict__ visit_count, int unit_max, double* __restrict__ partial) {
   // walks the sorted bodies [t_first, t_first + n) (a sharded run gives each rank a range)
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[4][kStack];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int replica = SPLIT ? (int)blockIdx.y : 0;
   const int rmask = SPLIT ? (int)gridDim.y - 1 : 0;  // K is a power of two
-  const int split_end = SPLIT ? level_base[split_level + 1] : 0;
   const int tl = blockIdx.x * kBlock + tid;  // position in the range
   const int t = t_first + tl;                // position in the sorted body list
   const bool valid = tl < n;
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   const unsigned long long m0 = __ballot(valid);
   if (m0 == 0ull) return;  // wave-uniform
   int sp = 0;
-  if (lane == 0) stk[w][0] = make_int4(0, 1, (int)(unsigned)(m0 & 0xffffffffull), (int)(unsigned)(m0 >> 32));
+  // entry = (first child, child count | parent-is-shared << 8, 64-bit lane mask); the root's "parent" is shared
+  if (lane == 0) stk[w][0] = make_int4(0, 1 | 256, (int)(unsigned)(m0 & 0xffffffffull), (int)(unsigned)(m0 >> 32));
   sp = 1;
   __builtin_amdgcn_wave_barrier();
   unsigned long long visited = 0;
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   while (sp > 0) {
     sp--;
     const int4 e = stk[w][sp];
-    const int c0 = rfl(e.x), cn = rfl(e.y);
+    const int c0 = rfl(e.x), cnf = rfl(e.y), cn = cnf & 0xff;
+    const bool pshared = SPLIT && (cnf & 256);
     const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.w) << 32) | (unsigned)rfl(e.z);
     const bool in = (M >> lane) & 1ull;
     // the whole sibling group (<= 8 consecutive 32-byte records) is fetched up front with
@@ -429,10 +432,11 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       const NodeRec nd = rec[k];
       // (a massless node, :161-162, needs no test of its own: it contributes m * g = 0 if accepted and
       // only massless descendants if opened)
-      bool mine = true, descend = true;  // wave-uniform
-      if (SPLIT && c0 + k < split_end) {
+      bool mine = true, shared = false;  // wave-uniform
+      if (SPLIT && pshared) {
+        shared = nd.count > unit_max;
         mine = ((c0 + k) & rmask) == replica;
-        descend = mine || (int)(nd.child & 0x0fffffffu) < split_end;
+        if (!shared && !mine) continue;  // another replica's unit
       }
       if (nd.child == 0u) {
         if (!mine) continue;
@@ -476,9 +480,9 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       // lanes of the group's mask that must open the node: scalar mask arithmetic on the compare
       // result (a ballot of `in && !far` goes through a VGPR and a second compare)
       const unsigned long long O = M & ~__ballot(far);
-      if (O != 0ull && descend) {
+      if (O != 0ull) {
         if (lane == 0)
-          stk[w][sp] = make_int4((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28),
+          stk[w][sp] = make_int4((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28) | (shared ? 256 : 0),
                                  (int)(unsigned)(O & 0xffffffffull), (int)(unsigned)(O >> 32));
         sp++;
       }
@@ -764,20 +768,21 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   if (n == 0) return NBODY_HIP_OK;
   // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
   int K = 1;
-  while (K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitBudget) K *= 2;
+  while (K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitAuto) K *= 2;
   if (g->tune_replicas > 0) {
     K = 1;
     while (K < g->tune_replicas && K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitBudget) K *= 2;
   }
-  if (K < 4 && g->tune_replicas <= 0) K = 1;  // measured: two replicas do not pay for the shared zone
-  int split_level = g->tune_split_level > 0 ? g->tune_split_level : 3;
-  if (split_level > g->max_depth - 1) split_level = g->max_depth - 1;
-  if (split_level < 1) K = 1;
+  // ownership units of at most n_total / 96 bodies (of the whole tree, not of the walked range): measured
+  // best at K x (units per replica) ~ 64..128 for every K (tools/bh_split_sweep.py)
+  const size_t units = g->tune_split_level > 0 ? (size_t)g->tune_split_level * (size_t)K : 96;
+  int unit_max = (int)(g->built_count / units);
+  if (unit_max < 1) unit_max = 1;
   const bool guard = eps2 < 1e-12f;
 #define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
                      g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,                     \
-                     g->d_level_base, split_level, g->d_partial)
+                     unit_max, g->d_partial)
   if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
   } else {
@@ -822,11 +827,11 @@ extern "C" int nbody_hip_tree_count_visits(nbody_hip_tree* g, int enable) {
   return NBODY_HIP_OK;
 }
 
-// experiments: replicas / split level of the split traversal (0 = automatic)
+// experiments: replicas / units per replica of the split traversal (0 = automatic)
 extern "C" int nbody_hip_tree_tuning(nbody_hip_tree* g, int replicas, int split_level) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
-  if (replicas < 0 || replicas > kMaxReplicas || split_level < 0 || split_level > kMaxDepth - 1)
-    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "replicas must be in [0, %d], split_level in [0, %d]", kMaxReplicas, kMaxDepth - 1);
+  if (replicas < 0 || replicas > kMaxReplicas || split_level < 0 || split_level > 1024)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "replicas must be in [0, %d], units per replica in [0, 1024]", kMaxReplicas);
   g->tune_replicas = replicas;
   g->tune_split_level = split_level;
   return NBODY_HIP_OK;

@@ -257,11 +257,11 @@ def test_split_walk_equals_plain_walk(nb, ctx, n, eps, max_depth):
     tree.computeForces(d, 0.6, 1.0, eps)
     plain = acc_of(d)
     assert np.isfinite(plain).all()
-    for replicas, level in ((2, 1), (4, 2), (16, 3), (16, 5), (8, 9), (0, 0)):
+    for replicas, level in ((2, 1), (4, 2), (16, 3), (16, 64), (8, 1024), (0, 0)):  # (replicas, units per replica)
         tree.tuning(replicas, level)
         tree.computeForces(d, 0.6, 1.0, eps)
         a = acc_of(d)
-        assert rel_err(a, plain).max() < 2e-6, (replicas, level)
+        assert rel_err(a, plain).max() < 5e-6, (replicas, level)
         tree.computeForces(d, 0.6, 1.0, eps)
         assert np.array_equal(acc_of(d), a), (replicas, level)
     with pytest.raises(nb.ValidationException):
@@ -308,10 +308,10 @@ def test_range_walks_equal_whole_walk(nb, ctx, n, parts):
         got = out.cpu().numpy()
         assert np.isfinite(got).all()            # every row written by some range
         assert (got[:, 3] == 0).all()
-        if n > 262144 // 4:                       # plain walk on both sides: bit for bit
+        if n // parts > 262144 // 2:              # plain walk on both sides: bit for bit
             assert np.array_equal(got[:, :3], whole)
         else:                                     # the split walk's replica count depends on the range length
-            assert rel_err(got[:, :3], whole).max() < 2e-6
+            assert rel_err(got[:, :3], whole).max() < 5e-6
         with pytest.raises(nb.ValidationException):
             check(lib.nbody_hip_tree_compute_forces_packed(h, n - 5, 6, 0.5, 1.0, 0.05, out.data_ptr()))
         check(lib.nbody_hip_tree_compute_forces_packed(h, n, 0, 0.5, 1.0, 0.05, out.data_ptr()))  # empty range: no-op

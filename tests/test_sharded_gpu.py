@@ -173,7 +173,7 @@ def test_sharded_tree_on_gpu(tmp_path, world, n, nb, ctx):
         integ.integrate(d, fc, 1e-3)
     ref_pos = np.stack([d.pos_x.cpu().numpy(), d.pos_y.cpu().numpy(), d.pos_z.cpu().numpy()], 1)
     ref_acc = np.stack([d.acc_x.cpu().numpy(), d.acc_y.cpu().numpy(), d.acc_z.cpu().numpy()], 1)
-    if n // world > 131072:
+    if n // world > 262144 // 2:
         assert np.array_equal(got["acc"][:, :3], ref_acc)
         assert np.array_equal(got["pos"][:, :3], ref_pos)
     else:

@@ -1,4 +1,4 @@
-"""Split-traversal sweep: traversal time vs replicas / split level at small N (tools, not product)."""
+"""Split-traversal sweep: traversal time vs replicas / units per replica at small N (tools, not product)."""
 import os
 import sys
 
@@ -33,14 +33,14 @@ for icname in ("plummer", "two_galaxies"):
         line = f"{icname} N={n}: build {tb:.0f}us |"
         ref = None
         for K in (1, 4, 8, 16):
-            for sl in ((0,) if K == 1 else (2, 3, 4)):
+            for sl in ((0,) if K == 1 else (2, 4, 8, 16, 32)):
                 tree.tuning(K, sl)
                 t = timed(lambda: tree.computeForces(d, 0.5, 1.0, 0.05))
                 a = acc_of(d)
                 if ref is None:
                     ref = a
                 err = np.abs(a - ref).max() / np.abs(ref).max()
-                line += f" K{K}/L{sl} {t:.0f}us" + (f"(!{err:.1e})" if err > 1e-6 else "")
+                line += f" K{K}/u{sl} {t:.0f}us" + (f"(!{err:.1e})" if err > 1e-6 else "")
         tree.tuning(0, 0)
         t = timed(lambda: tree.computeForces(d, 0.5, 1.0, 0.05))
         print(line + f" | auto {t:.0f}us", flush=True)
