@@ -306,21 +306,41 @@ __global__ __launch_bounds__(kPrefixBlock) void prefix_bodies_kernel(const float
     const double mb = (double)p.w;
     s[0] += mb * (double)p.x; s[1] += mb * (double)p.y; s[2] += mb * (double)p.z; s[3] += mb;
   }
+  // exclusive scan of the per-thread totals: inclusive scan inside each wave by shuffles, then the 16
+  // wave totals by one wave through LDS (two barriers; fixed summation tree = deterministic)
+  const int lane = tid & 63, wv = tid >> 6;
+  double inc[4];
 #pragma unroll
-  for (int c = 0; c < 4; c++) tot[c][tid] = s[c];
-  __syncthreads();
-  for (int off = 1; off < kPrefixBlock; off <<= 1) {  // inclusive scan of the per-thread totals
-    double v[4];
+  for (int c = 0; c < 4; c++) {
+    double v = s[c];
 #pragma unroll
-    for (int c = 0; c < 4; c++) v[c] = tid >= off ? tot[c][tid - off] : 0.0;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; c++) tot[c][tid] += v[c];
-    __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+      const double u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    inc[c] = v;
+    if (lane == 63) tot[c][wv] = v;
   }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      double v = lane < kPrefixBlock / 64 ? tot[c][lane] : 0.0;
+#pragma unroll
+      for (int off = 1; off < kPrefixBlock / 64; off <<= 1) {
+        const double u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+      }
+      if (lane < kPrefixBlock / 64) tot[c][64 + lane] = v;  // inclusive scan of the wave totals
+    }
+  }
+  __syncthreads();
   double run[4];
 #pragma unroll
-  for (int c = 0; c < 4; c++) run[c] = tid > 0 ? tot[c][tid - 1] : 0.0;
+  for (int c = 0; c < 4; c++) {
+    const double before = __shfl_up(inc[c], 1, 64);  // lanes of this wave before this one
+    run[c] = (wv > 0 ? tot[c][64 + wv - 1] : 0.0) + (lane > 0 ? before : 0.0);
+  }
   for (int k = k0; k < k1; k++) {  // P[k] = sums over the bodies before k
     P[k] = make_double4(run[0], run[1], run[2], run[3]);
     const float4 p = sorted[k];
