@@ -220,7 +220,7 @@ def main(argv=None) -> int:
         print(appCliUsage())
         return 0
     if o.list_algorithms:
-        print("direct-n2     O(N^2)      exact all-pairs (symmetric kernel from N = 32768)")
+        print("direct-n2     O(N^2)      exact all-pairs (symmetric kernel from N = 12288)")
         print("barnes-hut    O(N log N)  octree, opening angle --theta")
         print("spatial-hash  O(N)        cell grid, short range (--cell-size, --cutoff)")
         return 0
