@@ -245,7 +245,8 @@ def test_full_size_properties(nb, oracle, ctx):
 # the symmetric (action = -reaction) kernel at sizes where it is the default, all register
 # blockings, ragged N (padding inside the last superblock), even and odd superblock counts
 @pytest.mark.parametrize("equal_mass", [True, False])
-@pytest.mark.parametrize("n,tpl", [(33000, 0), (40000, 2), (50001, 4), (70000, 6), (100003, 8), (65536, 0)])
+@pytest.mark.parametrize("n,tpl", [(33000, 0), (40000, 2), (50001, 4), (70000, 6), (100003, 8), (65536, 0),
+                                   (13000, 0), (90001, 16)])
 def test_symmetric_kernel_vs_oracle(nb, oracle, ctx, n, tpl, equal_mass):
     ic = nb.ic.plummer(n, seed=n)
     if not equal_mass:  # the general-mass instantiation (the equal-mass one exits on the device flag)
@@ -296,6 +297,29 @@ def test_pair_kernel(nb, oracle, ctx, masses):
         assert rel_err(acc_b.cpu().numpy()[:, :3], 2 * rb.cpu().numpy()[:, :3]).max() < TOL
     with pytest.raises(nb.ValidationException):
         nb.direct_forces_pair_packed(ctx, a, b, 1.0, 0.0, acc_a, acc_b)
+
+
+# shard-sized sets: both >= 49,152 bodies -> 16 bodies per lane with the fp64 sums in LDS
+@pytest.mark.parametrize("masses", ["equal", "random"])
+def test_pair_kernel_shard_sizes(nb, ctx, masses):
+    n = 110003
+    ic = nb.ic.plummer(n, seed=78)
+    if masses == "random":
+        ic["mass"] = (ic["mass"] * np.random.default_rng(6).uniform(0.5, 2.0, n)).astype(np.float32)
+    p = packed(ic)
+    na = 55001
+    a, b = p[:na].contiguous(), p[na:].contiguous()
+    acc_a = torch.full((na, 4), 3.0, device="cuda")
+    acc_b = torch.full((n - na, 4), 3.0, device="cuda")
+    nb.direct_forces_pair_packed(ctx, a, b, 1.0, 1e-6, acc_a, acc_b)
+    try:
+        ctx.tuning(1, 4, 0)  # the one-sided kernel (verified against the oracle above) as the reference
+        ra = nb.direct_forces_packed(ctx, a, b, 1.0, 1e-6)
+        rb = nb.direct_forces_packed(ctx, b, a, 1.0, 1e-6)
+    finally:
+        ctx.tuning()
+    assert rel_err(acc_a.cpu().numpy()[:, :3], ra.cpu().numpy()[:, :3]).max() < TOL
+    assert rel_err(acc_b.cpu().numpy()[:, :3], rb.cpu().numpy()[:, :3]).max() < TOL
 
 
 # the sharded "pair" mode's arithmetic with the HIP kernels, W ranks emulated one after the other
