@@ -42,6 +42,10 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 
 namespace nbh {
 
+#ifndef NBH_BH_XCD
+#define NBH_BH_XCD 1
+#endif
+
 constexpr int kMaxDepth = 10;      // 30-bit Morton keys
 constexpr int kStack = 8 * (kMaxDepth + 2);
 constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
@@ -416,7 +420,13 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int replica = SPLIT ? (int)blockIdx.y : 0;
   const int rmask = SPLIT ? (int)gridDim.y - 1 : 0;  // K is a power of two
-  const int tl = blockIdx.x * kBlock + tid;  // position in the range
+  // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch); giving XCD x the x-th
+  // contiguous eighth of the Morton-ordered targets keeps neighbouring walks -- which fetch the same
+  // nodes -- behind the same L2
+  const int nblk = (int)gridDim.x, xcd = (int)blockIdx.x % 8;
+  int bid = xcd * (nblk / 8) + min(xcd, nblk % 8) + (int)blockIdx.x / 8;  // a bijection for any nblk
+  if (NBH_BH_XCD == 0) bid = (int)blockIdx.x;
+  const int tl = bid * kBlock + tid;  // position in the range
   const int t = t_first + tl;                // position in the sorted body list
   const bool valid = tl < n;
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
