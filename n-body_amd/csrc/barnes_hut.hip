@@ -501,9 +501,10 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       // :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the same
       // inequality without the IEEE division sequence; the oracle uses the same form
       const bool far = nd.size2 < theta2 * dist2;
-      if (in && far && mine) {  // skipped by the whole wave when every lane opens the node (common)
+      {  // one select on the factor; a masked region is if-converted by the compiler into three selects on
+         // the sums anyway (measured: -4..8 % against `if (in && far && mine) {...}`)
         const float inv = __builtin_amdgcn_rsqf(dist2);
-        const float f = (nd.mass * inv) * (inv * inv);
+        const float f = (in && far && mine) ? (nd.mass * inv) * (inv * inv) : 0.f;
         ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
       }
       // lanes of the group's mask that must open the node: scalar mask arithmetic on the compare
