@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const int c0 = rfl(e.x), cnf = rfl(e.y), cn = cnf & 0xff;
     const bool pshared = SPLIT && (cnf & 256);
     const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.w) << 32) | (unsigned)rfl(e.z);
-    const bool in = (M >> lane) & 1ull;
+    const bool in = __builtin_amdgcn_inverse_ballot_w64(M);  // the scalar mask as the lane predicate: no VALU
     // the whole sibling group (<= 8 consecutive 32-byte records) is fetched up front with
     // wave-uniform (scalar-cache) loads: ONE memory round trip per group instead of one per node.
     // The node array is padded by 8 records, so reading past a short group is harmless.
