@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
           const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
           bool ok = in && (nd.first != t);
           if (GUARD) ok = ok && (d2 > 0.f);
-          const float f = ok ? (nd.mass * inv) * (inv * inv) : 0.f;
+          const float f = ok ? ((nd.mass * inv) * inv) * inv : 0.f;
           ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
           continue;
         }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
           const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
           bool ok = in && (q != t);
           if (GUARD) ok = ok && (d2 > 0.f);
-          const float f = ok ? (s.w * inv) * (inv * inv) : 0.f;
+          const float f = ok ? ((s.w * inv) * inv) * inv : 0.f;
           ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
         }
         continue;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       {  // one select on the factor; a masked region is if-converted by the compiler into three selects on
          // the sums anyway (measured: -4..8 % against `if (in && far && mine) {...}`)
         const float inv = __builtin_amdgcn_rsqf(dist2);
-        const float f = (in && far && mine) ? (nd.mass * inv) * (inv * inv) : 0.f;
+        const float f = (in && far && mine) ? ((nd.mass * inv) * inv) * inv : 0.f;
         ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
       }
       // lanes of the group's mask that must open the node: scalar mask arithmetic on the compare
