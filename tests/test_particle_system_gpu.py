@@ -125,3 +125,34 @@ def test_headless_benchmark_mode(nb, ctx, tmp_path, method):
     assert nb.cli.runBenchmarkMode(o2, out=buf2) == 0
     assert "Imported 4096 particles" in buf2.getvalue()
     assert json.loads(buf2.getvalue().strip().splitlines()[-1])["benchmarks"][0]["particle_count"] == 4096
+
+
+# resource cycling: handles are released (device memory returns to where it was)
+def test_create_destroy_cycles_release_memory(nb, ctx):
+    import gc
+    import torch
+    from gpu_util import to_device
+    ic = nb.ic.plummer(20000, seed=2)
+    d, _ = to_device(nb, ic)
+
+    def cycle():
+        bh = nb.BarnesHutCalculator(0.5)
+        bh.computeForces(d)
+        sh = nb.SpatialHashCalculator(1.0, 1.0)
+        sh.computeForces(d)
+        ps = nb.ParticleSystem()
+        ps.initialize(nb.SimulationConfig(particle_count=5000, force_method=nb.ForceMethod.BARNES_HUT))
+        ps.update(1e-3)
+        del bh, sh, ps
+        gc.collect()
+        torch.cuda.synchronize()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)  # no growth beyond allocator noise
