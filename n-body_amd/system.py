@@ -18,10 +18,10 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import ic as _ic
 from ._lib import ValidationException
-from .api import (BarnesHutCalculator, ForceMethod, InitDistribution, Integrator, ParticleData,
-                  ParticleDataManager, SimulationConfig, SpatialHashCalculator,
+from .api import (BarnesHutCalculator, DiskDistParams, ForceMethod, InitDistribution, Integrator, ParticleData,
+                  ParticleDataManager, ParticleInitializer, SimulationConfig, SpatialHashCalculator,
+                  SphericalDistParams, UniformDistParams,
                   createForceCalculator, validateSimulationConfig, validateSoftening,
                   validateTheta, validateTimeStep, _finite)
 
@@ -175,14 +175,17 @@ class ParticleSystem:
         n = config.particle_count
         self._allocate(n)
         if initial_conditions is None:
+            # particle_system.cpp:53-79, default seed 42 (particle_data.hpp:38-57): the same bodies as the
+            # reference's C++ ParticleSystem under libstdc++ (api.ParticleInitializer)
             if config.init_distribution == InitDistribution.UNIFORM:
-                initial_conditions = _ic.uniform_box(n, seed=42, lo=-10.0, hi=10.0)
+                ParticleInitializer.initUniform(self.h_particles_, UniformDistParams((-10, -10, -10), (10, 10, 10)))
             elif config.init_distribution == InitDistribution.SPHERICAL:
-                initial_conditions = _ic.sphere(n, seed=42, radius=10.0)
+                ParticleInitializer.initSpherical(self.h_particles_, SphericalDistParams((0, 0, 0), 10.0))
             else:
-                initial_conditions = _ic.disk(n, seed=42, radius=10.0, thickness=1.0, rotation_speed=0.5)
-        for k, v in initial_conditions.items():
-            getattr(self.h_particles_, k)[:] = v
+                ParticleInitializer.initDisk(self.h_particles_, DiskDistParams((0, 0, 0), 10.0, 1.0, rotation_speed=0.5))
+        else:
+            for k, v in initial_conditions.items():
+                getattr(self.h_particles_, k)[:] = v
         ParticleDataManager.copyToDevice(self.d_particles_, self.h_particles_)
         self._create_calculator()
         self.integrator_ = Integrator(config.cuda_block_size)

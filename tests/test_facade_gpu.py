@@ -109,3 +109,48 @@ def test_sharded_bench_rehearsal_two_ranks(workload, n):
     if workload == "direct":
         assert doc["metric"] == "pair_interactions_per_s" and doc["scaling"] == "strong"
         assert "shard pair" in doc["roofline"]["kernel"] and doc["roofline"]["frac"] > 0
+
+
+# a13 end to end: the REFERENCE's own ParticleSystem (its unmodified particle_system.cpp on the facade,
+# oracle/ref_system_driver.cpp) against the Python ParticleSystem, same config, same steps; both write
+# the reference's checkpoint format.  Uniform-box bodies are bit-identical on both sides (libstdc++
+# stream restated in api.ParticleInitializer), so the whole trajectory must be; sphere / disk bodies
+# go through cbrt / sin / cos / acos, where numpy and glibc may differ in the last ulp.
+@pytest.mark.parametrize("method,dist,n,steps", [(0, 0, 3000, 5), (1, 0, 3000, 5), (2, 0, 3000, 5),
+                                                 (1, 1, 2000, 3), (0, 2, 2000, 3), (0, 0, 40000, 2)])
+def test_reference_particle_system_equals_python_system(tmp_path, method, dist, n, steps):
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import nbody_amd as nb
+    exe = _need("ref_system_driver")
+    out = tmp_path / "ref.nbody"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIB + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    dt = 0.001
+    r = subprocess.run([exe, str(method), str(dist), str(n), str(steps), str(dt), str(out)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = nb.Serializer.load(str(out))
+    ps = nb.ParticleSystem()
+    ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod(method),
+                                      init_distribution=nb.InitDistribution(dist), dt=dt))
+    for _ in range(steps):
+        ps.update(dt)
+    mine = ps.getState()
+    assert mine.particle_count == ref.particle_count == n
+    assert abs(mine.simulation_time - ref.simulation_time) < 1e-9
+    assert mine.force_method == ref.force_method
+    assert np.float32(mine.G) == np.float32(ref.G) and np.float32(mine.softening) == np.float32(ref.softening)
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass"):
+        a, b = getattr(mine, k), getattr(ref, k)
+        if dist == 0 and not (method == 0 and n >= 12288):   # uniform box; the symmetric direct kernel sums by atomics
+            assert np.array_equal(a, b), k
+        else:
+            assert np.allclose(a, b, rtol=2e-5, atol=2e-5), k
+    # the energies the reference program printed
+    m = re.search(r"KE ([-0-9.e+]+) PE ([-0-9.e+]+)", r.stdout)
+    ke, pe = float(m.group(1)), float(m.group(2))
+    assert abs(ps.computeKineticEnergy() - ke) <= 1e-5 * abs(ke) + 1e-7
+    assert abs(ps.computePotentialEnergy() - pe) <= 1e-5 * abs(pe)

@@ -158,3 +158,18 @@ def test_initializers_match_cpp_facade(nb, tmp_path, kind, seed, n):
     else:
         assert np.array_equal(got[6], ref[6])  # masses: no transcendental involved
         assert np.allclose(got, ref, rtol=0, atol=4e-6)  # a few ulp of |x| <= 11 through cbrt/sin/cos/acos
+
+
+# a13: ParticleSystem::initialize seeds its bodies with the reference's recipe (particle_system.cpp:53-79,
+# seed 42): the Python system starts from the same bodies as the C++ one (checked host-side, no GPU:
+# the initialiser output that initialize() uploads)
+@pytest.mark.skipif(not os.path.exists(IC_DUMP), reason="facade not built")
+def test_particle_system_default_bodies_are_the_reference_recipe(nb):
+    h = nb.ParticleData()
+    nb.ParticleDataManager.allocateHost(h, 500)
+    nb.ParticleInitializer.initUniform(h, nb.UniformDistParams((-10, -10, -10), (10, 10, 10)))
+    assert (np.abs(h.pos_x) <= 10).all() and (h.mass == 1.0).all()
+    # the same call the system makes, bit-identical to libstdc++'s stream for seed 42
+    u = np.random.RandomState(42)._bit_generator.random_raw(4).astype(np.uint32)
+    x0 = np.float32(u[0]) / np.float32(4294967296.0) * np.float32(20.0) + np.float32(-10.0)
+    assert h.pos_x[0] == x0
