@@ -5,9 +5,12 @@ scope.  Run:  python -m nbody_amd.cli --particles 65536 --method barnes-hut --be
 """
 from __future__ import annotations
 
+import re
 import sys
 import time
 from dataclasses import dataclass
+
+import numpy as np
 
 from ._lib import ValidationException
 from .api import (ForceMethod, InitDistribution, SimulationConfig, validateParticleCountRange,
@@ -39,21 +42,43 @@ class AppCliOptions:  # include/nbody/app_cli.hpp:8-26
     show_diagnostics: bool = False
 
 
+_STOULL = re.compile(r"[ \t\n\v\f\r]*([+-]?)([0-9]+)")
+_STOF = re.compile(r"[ \t\n\v\f\r]*([+-]?(?:0[xX](?:[0-9a-fA-F]+\.?[0-9a-fA-F]*|\.[0-9a-fA-F]+)(?:[pP][+-]?[0-9]+)?"
+                   r"|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?|[iI][nN][fF](?:[iI][nN][iI][tT][yY])?"
+                   r"|[nN][aA][nN](?:\([0-9a-zA-Z_]*\))?))")
+
+
 def _size(value, flag):
-    try:
-        v = int(value, 10)
-        if v < 0:
-            raise ValueError
-        return v
-    except ValueError:
-        raise ValidationException(f"Invalid numeric value for {flag}: {value}") from None
+    """std::stoull(value) as app_cli.cpp:30-36 uses it: leading blanks and a sign are accepted, the
+    longest decimal prefix is converted (trailing text ignored), a minus sign wraps modulo 2^64."""
+    m = _STOULL.match(value)
+    if not m or int(m.group(2)) > 0xFFFFFFFFFFFFFFFF:
+        raise ValidationException(f"Invalid numeric value for {flag}: {value}")
+    v = int(m.group(2))
+    return (-v) % (1 << 64) if m.group(1) == "-" else v
 
 
 def _float(value, flag):
-    try:
-        return float(value)
-    except ValueError:
-        raise ValidationException(f"Invalid numeric value for {flag}: {value}") from None
+    """std::stof(value) (app_cli.cpp:38-44): strtof's longest prefix (decimal, hex, inf, nan), a result
+    outside float's range (or a nonzero one that underflows it) is an error."""
+    m = _STOF.match(value)
+    if not m:
+        raise ValidationException(f"Invalid numeric value for {flag}: {value}")
+    text = m.group(1)
+    low = text.lower().lstrip("+-")
+    if low.startswith("0x"):
+        v = float.fromhex(text)
+    elif low.startswith("nan"):
+        v = float("nan")
+    else:
+        v = float(text)
+    if v == v and abs(v) != float("inf"):
+        with np.errstate(over="ignore"):
+            f32 = float(np.float32(v))
+        if abs(f32) == float("inf") or (v != 0.0 and abs(f32) < 1.1754943508222875e-38):
+            raise ValidationException(f"Invalid numeric value for {flag}: {value}")
+        return f32
+    return v
 
 
 def parseAppCliOptions(argv) -> AppCliOptions:

@@ -95,6 +95,17 @@ class BenchmarkRunRecord:
     phase_timings: list = field(default_factory=list)
 
 
+def _escape(text: str) -> str:
+    """escapeJson of the reference (performance_observability.cpp:10-35): only backslash, quote, newline,
+    carriage return and tab are escaped; every other character goes out as it is."""
+    return (text.replace("\\", "\\\\").replace("\"", "\\\"").replace("\n", "\\n").replace("\r", "\\r")
+            .replace("\t", "\\t"))
+
+
+def _q(text: str) -> str:
+    return "\"" + _escape(text) + "\""
+
+
 def _num(v) -> str:
     # the reference streams doubles with operator<< (6 significant digits, no trailing zeros):
     # 256.0 -> "256", 1.25 -> "1.25"
@@ -103,14 +114,14 @@ def _num(v) -> str:
 
 def _number_map(m: dict) -> str:
     # std::map iterates in key order
-    return "{" + ",".join(f"{json.dumps(k)}:{_num(m[k])}" for k in sorted(m)) + "}"
+    return "{" + ",".join(f"{_q(k)}:{_num(m[k])}" for k in sorted(m)) + "}"
 
 
 def serializeBenchmarkRunRecord(r: BenchmarkRunRecord) -> str:
     phases = ",".join(
-        "{" + f"\"name\":{json.dumps(p.name)},\"total_duration_ms\":{_num(p.total_duration_ms)},"
+        "{" + f"\"name\":{_q(p.name)},\"total_duration_ms\":{_num(p.total_duration_ms)},"
         f"\"samples\":{p.samples}" + "}" for p in r.phase_timings)
-    return ("{" + f"\"benchmark_name\":{json.dumps(r.benchmark_name)},"
+    return ("{" + f"\"benchmark_name\":{_q(r.benchmark_name)},"
             f"\"force_method\":\"{forceMethodToString(r.force_method)}\","
             f"\"particle_count\":{int(r.particle_count)},\"iterations\":{int(r.iterations)},"
             f"\"metrics\":{_number_map(r.metrics)},\"parameters\":{_number_map(r.parameters)},"

@@ -1,16 +1,23 @@
 """f2 / f3 rows, CPU-only: option parsing (tests/test_app_cli.cpp:7-76), usage text, benchmark
 record JSON (tests/test_performance_observability.cpp:7-24) and the phase profiler (:26-41)."""
 import json
+import os
+import subprocess
 import time
 
+import numpy as np
+
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_parses_structured_simulation_options(nb):
     o = nb.cli.parseAppCliOptions(["nbody_sim", "--particles", "2048", "--method", "barnes-hut", "--dt", "0.002",
                                    "--theta", "0.7", "--softening", "0.05", "--benchmark", "--benchmark-steps", "12"])
     assert o.particle_count == 2048 and o.force_method == nb.ForceMethod.BARNES_HUT
-    assert (o.dt, o.barnes_hut_theta, o.softening) == (0.002, 0.7, 0.05)
+    f32 = lambda v: float(np.float32(v))  # noqa: E731  (options are C floats in the reference)
+    assert (o.dt, o.barnes_hut_theta, o.softening) == (f32(0.002), f32(0.7), f32(0.05))
     assert o.benchmark_mode and o.benchmark_steps == 12
 
 
@@ -89,3 +96,80 @@ def test_scoped_phase_profiler_accumulates(nb, tmp_path):
         {"name": "p", "total_duration_ms": 2.5, "samples": 3}]
     with pytest.raises(RuntimeError, match="Failed to open benchmark output file"):
         ob.writeBenchmarkRunRecords(str(tmp_path / "nodir" / "x.json"), [r])
+
+
+# f3 pinned to the reference's own parser: oracle/_ref/ref_cli_driver runs parseAppCliOptions compiled
+# from /root/reference/src/core/app_cli.cpp (oracle/Makefile.ref; host only) on the same arguments
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "ref_cli_driver")
+ARGV_CASES = [
+    [], ["4096"], ["--particles", "500", "--method", "barnes-hut", "--theta", "0.7"],
+    ["--method", "spatial_hash", "--cell-size", "0.5", "--cutoff", "1.5", "--softening", "0"],
+    ["--method", "direct_n2", "--dt", "1e-3", "--gravity", "6.674e-11"],
+    ["--benchmark-steps", "77"], ["--benchmark-output", "out.json"], ["--benchmark"],
+    ["--export", "a.nbody", "--export-format", "nbody", "--import", "b.nbody"],
+    ["--list-algorithms"], ["--diagnostics"], ["-h"], ["--help", "123"],
+    ["12abc"], ["+7"], [" 42"], ["1e3"], ["0x10"], ["-5"], ["abc"], [""],
+    ["--dt", ".5"], ["--dt", "5."], ["--dt", "1.5x"], ["--dt", "inf"], ["--dt", "nan"], ["--dt", "-0.1"],
+    ["--dt", "1e40"], ["--dt", "1e-50"], ["--dt", "0x1p-4"], ["--dt", "abc"], ["--dt"],
+    ["--theta", "2.5"], ["--theta", "-1"], ["--softening", "-0.5"], ["--gravity", "0"], ["--gravity", "-2"],
+    ["--cell-size", "0"], ["--cutoff", "-1"], ["--benchmark-steps", "0"], ["--particles", "0"],
+    ["--particles", "100000001"], ["--method", "fmm"], ["--bogus"], ["--particles"],
+    ["100", "200"], ["--particles", "10", "20"],
+]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("args", ARGV_CASES, ids=lambda a: " ".join(a) or "(none)")
+def test_cli_parser_equals_reference_parser(nb, args):
+    from nbody_amd import cli
+    r = subprocess.run([REF_CLI] + args, capture_output=True, text=True, timeout=30)
+    try:
+        o = cli.parseAppCliOptions(["prog"] + args)
+        mine = None
+    except nb.ValidationException as e:
+        o, mine = None, str(e)
+    if r.returncode != 0:
+        ref_msg = r.stdout.rstrip("\n").replace("error: ", "", 1).replace("Validation Error: ", "", 1)
+        assert mine == ref_msg, (mine, r.stdout)
+        return
+    assert mine is None, (mine, r.stdout)
+    ref = dict(line.split(" ", 1) if " " in line else (line, "") for line in r.stdout.splitlines())
+    f32 = lambda v: float(np.float32(v))  # noqa: E731
+    assert int(ref["particle_count"]) == o.particle_count
+    assert int(ref["force_method"]) == int(o.force_method)
+    for key, val in (("dt", o.dt), ("G", o.G), ("softening", o.softening), ("theta", o.barnes_hut_theta),
+                     ("cell_size", o.spatial_hash_cell_size), ("cutoff", o.spatial_hash_cutoff)):
+        assert f32(float(ref[key])) == f32(val), key
+    assert int(ref["benchmark_mode"]) == int(o.benchmark_mode) and int(ref["benchmark_steps"]) == o.benchmark_steps
+    assert ref["benchmark_output"] == o.benchmark_output_path
+    assert ref["export_path"] == o.export_path and ref["export_format"] == o.export_format
+    assert ref["import_path"] == o.import_path
+    assert int(ref["show_help"]) == int(o.show_help) and int(ref["list_algorithms"]) == int(o.list_algorithms)
+    assert int(ref["show_diagnostics"]) == int(o.show_diagnostics)
+
+
+# f2 pinned to the reference's own serializer: oracle/_ref/ref_observability_driver prints what
+# serializeBenchmarkRunRecords / PhaseProfiler (compiled from the reference's performance_observability.cpp)
+# produce for a fixed set of awkward records; the Python module must produce the same bytes
+REF_OBS = os.path.join(ROOT, "oracle", "_ref", "ref_observability_driver")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_OBS), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_benchmark_records_equal_reference_serializer(nb):
+    from nbody_amd import observability as ob
+    out = subprocess.run([REF_OBS], capture_output=True, timeout=30).stdout.decode("utf-8").split("\n")
+    a = ob.BenchmarkRunRecord(benchmark_name="force.direct_n2", force_method=nb.ForceMethod.DIRECT_N2,
+                              particle_count=1048576, iterations=20)
+    a.metrics = {"wall_time_ms": 156.793342, "steps_per_s": 6.3778218, "pair_interactions_per_s": 7.0124892e12,
+                 "zero": 0.0, "neg_zero": -0.0, "tiny": 1.25e-7, "exact": 256.0, "third": 1.0 / 3.0}
+    a.parameters = {"dt": 0.001, "softening": 0.1, "gpus": 1.0, "big": 1e21, "negative": -42.5}
+    prof = ob.PhaseProfiler()
+    prof.record("simulation.update", 1.5)
+    prof.record("force", 0.25)
+    prof.record("simulation.update", 2.75)
+    a.phase_timings = prof.snapshot()
+    b = ob.BenchmarkRunRecord(benchmark_name="quote\" backslash\\ newline\n tab\t cr\r unicode \u03b1 end", force_method=7)
+    b.metrics = {"inf": float("inf"), "nan": float("nan"), "key \"q\"": 1.0}
+    c = ob.BenchmarkRunRecord(benchmark_name="empty", force_method=nb.ForceMethod.SPATIAL_HASH)
+    assert ob.serializeBenchmarkRunRecords([a, b, c]) == out[0]
+    assert ob.serializeBenchmarkRunRecord(a) == out[1]
