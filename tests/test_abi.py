@@ -131,3 +131,55 @@ def test_ic_generators_are_deterministic(nb):
     assert r.max() < 10.6 and 0.5 < np.median(r) < 2.0  # Plummer half-mass radius ~1.3 a
     d = nb.ic.two_galaxies(1000)
     assert d["pos_x"].size == 1000
+
+
+# a14 pinned to the reference's own validators: oracle/_ref/ref_validate_driver runs the functions
+# compiled from /root/reference/src/utils/error_handling.cpp; same verdict and same message, value by value
+REF_VAL = os.path.join(ROOT, "oracle", "_ref", "ref_validate_driver")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_VAL), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_validators_equal_reference_validators(nb):
+    import struct
+    import subprocess
+
+    import numpy as np
+    from nbody_amd import api
+
+    def hexf(x):
+        return "%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+    floats = [0.0, -0.0, 1e-45, 1e-8, 1e-4, 1e-3, 0.5, 1.0, float(np.nextafter(np.float32(1), np.float32(2))), 1.5, 2.0,
+              float(np.nextafter(np.float32(2), np.float32(3))), 2.5, 100.0, 3e38, -1e-45, -0.1, -5.0,
+              float("inf"), float("-inf"), float("nan")]
+    counts = [0, 1, 2, 4096, 100000000, 100000001, 2 ** 40]
+    reqs, calls = [], []
+    for c in counts:
+        reqs.append(f"count {c}")
+        calls.append(lambda c=c: api.validateParticleCountRange(c))
+    for kind, fn in (("timestep", api.validateTimeStep), ("softening", api.validateSoftening), ("theta", api.validateTheta)):
+        for x in floats:
+            reqs.append(f"{kind} {hexf(x)}")
+            calls.append(lambda fn=fn, x=x: fn(float(np.float32(x))))
+    rng = np.random.default_rng(0)
+    pick = lambda seq: seq[int(rng.integers(len(seq)))]  # noqa: E731
+    for _ in range(300):  # random configs out of the same awkward values
+        cfg = dict(particle_count=pick(counts), dt=pick(floats), softening=pick(floats), barnes_hut_theta=pick(floats),
+                   G=pick(floats), cuda_block_size=pick([0, 1, 256, 1024, 1025, -3]), force_method=pick([0, 1, 2]),
+                   spatial_hash_cell_size=pick(floats), spatial_hash_cutoff=pick(floats))
+        reqs.append("config {particle_count} {} {} {} {} {cuda_block_size} {force_method} {} {}".format(
+            hexf(cfg["dt"]), hexf(cfg["softening"]), hexf(cfg["barnes_hut_theta"]), hexf(cfg["G"]),
+            hexf(cfg["spatial_hash_cell_size"]), hexf(cfg["spatial_hash_cutoff"]), **cfg))
+        f32 = {k: (float(np.float32(v)) if isinstance(v, float) else v) for k, v in cfg.items()}
+        f32["force_method"] = nb.ForceMethod(cfg["force_method"])
+        calls.append(lambda f32=f32: api.validateSimulationConfig(nb.SimulationConfig(**f32)))
+    out = subprocess.run([REF_VAL], input="\n".join(reqs) + "\n", capture_output=True, text=True, timeout=60)
+    ref = out.stdout.splitlines()
+    assert len(ref) == len(reqs)
+    for req, expected, call in zip(reqs, ref, calls):
+        try:
+            call()
+            got = "ok"
+        except nb.ValidationException as e:
+            got = "Validation Error: " + str(e)
+        assert got == expected, (req, got, expected)
