@@ -232,6 +232,9 @@ NBODY_HIP_API int nbody_hip_grid_compute_forces(nbody_hip_grid* grid, nbody_part
 /* ref: getGridDims / getTotalCells (spatial_hash_grid.hpp:20-24) + the padded bounding box. */
 NBODY_HIP_API int nbody_hip_grid_info(const nbody_hip_grid* grid, int dims[3], int* total_cells,
                                       float bbox_min[3], float bbox_max[3]);
+/* Number of bodies of the last build (0 before the first): the length of the per-body arrays
+ * copy_cell_data writes (the reference keeps it as the ParticleData count it was built from). */
+NBODY_HIP_API int nbody_hip_grid_count(const nbody_hip_grid* grid, size_t* built_count);
 /* ref: copyCellDataToHost :318-331 -- HOST output arrays (any may be NULL): cell_start/cell_end
  * [total_cells] (0/0 for an empty cell), particle_cells [count], sorted_indices [count].
  * Blocking. */

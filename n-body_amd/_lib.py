@@ -95,6 +95,7 @@ PROTOTYPES = {
     "nbody_hip_grid_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
     "nbody_hip_grid_info": (C.c_int, [_P, C.POINTER(C.c_int * 3), C.POINTER(C.c_int),
                                       C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
+    "nbody_hip_grid_count": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "nbody_hip_grid_copy_cell_data": (C.c_int, [_P, _P, _P, _P, _P]),
     "nbody_hip_grid_build_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "nbody_hip_grid_compute_forces_packed": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),

@@ -739,12 +739,21 @@ class Integrator:
             self._ctx = default_context()
         return self._ctx
 
+    @staticmethod
+    def _fusable(force_calc) -> bool:
+        return (type(force_calc) is DirectForceCalculator
+                and isinstance(force_calc.block_size_, int) and 1 <= force_calc.block_size_ <= 1024)
+
     def integrate(self, d_particles: ParticleData, force_calc: ForceCalculator, dt: float):
-        # integrator.cu:224-238
-        if isinstance(force_calc, DirectForceCalculator):
+        # integrator.cu:224-238.  The extension point is the virtual computeForces
+        # (force_calculator.hpp:36-58): the fused launch sequence is taken only for exactly the
+        # engine's own DirectForceCalculator, on that calculator's context, and only with a block
+        # size its computeForces would accept (otherwise the call below reports it).
+        if self._fusable(force_calc):
             s = d_particles.struct()
-            check(self.ctx._lib.nbody_hip_integrate_direct(
-                self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, 1))
+            fctx = force_calc.ctx
+            check(fctx._lib.nbody_hip_integrate_direct(
+                fctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, 1))
             return
         s = d_particles.struct()  # a_old <- a and the position update in one pass
         check(self.ctx._lib.nbody_hip_drift(self.ctx.handle, C.byref(s), dt))
@@ -767,10 +776,11 @@ class Integrator:
         if graph and isinstance(force_calc, SpatialHashCalculator):
             graph = False
         if not graph:
-            if isinstance(force_calc, DirectForceCalculator):
+            if self._fusable(force_calc):
                 s = d_particles.struct()
-                check(self.ctx._lib.nbody_hip_integrate_direct(
-                    self.ctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, steps))
+                fctx = force_calc.ctx
+                check(fctx._lib.nbody_hip_integrate_direct(
+                    fctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, steps))
             else:
                 for _ in range(steps):
                     self.integrate(d_particles, force_calc, dt)

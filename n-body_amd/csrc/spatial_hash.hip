@@ -627,6 +627,12 @@ extern "C" int nbody_hip_grid_info(const nbody_hip_grid* g, int dims[3], int* to
   return NBODY_HIP_OK;
 }
 
+extern "C" int nbody_hip_grid_count(const nbody_hip_grid* g, size_t* built_count) {
+  if (!g || !built_count) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  *built_count = g->built_count;
+  return NBODY_HIP_OK;
+}
+
 extern "C" int nbody_hip_grid_copy_cell_data(nbody_hip_grid* g, int* cell_start, int* cell_end,
                                              int* particle_cells, int* sorted_indices) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");

@@ -140,7 +140,11 @@ public:
   bool verifyTreeStructure() const;
   bool verifyMassConservation(const ParticleData* h_particles) const;
 private:
-  // reference data members (order kept so inline accessors compiled elsewhere stay valid)
+  // EXACTLY the reference's data members (barnes_hut_tree.hpp:57-74), same order and types:
+  // sizeof == 96 under both header sets, so a caller compiled against the reference's header
+  // (its tests build these objects on the stack) reserves what this constructor writes.
+  // The engine's handle lives in the d_nodes_ slot (the device node array belongs to the
+  // handle); the other two device pointers stay null.  Checked by oracle/layout_probe.cpp.
   OctreeNode* d_nodes_ = nullptr;
   int* d_sorted_indices_ = nullptr;
   unsigned int* d_morton_codes_ = nullptr;
@@ -150,9 +154,7 @@ private:
   int node_count_ = 0;
   int max_depth_ = 0;
   Vec3 bbox_min_, bbox_max_;
-  // this implementation
-  nbody_hip_tree* tree_ = nullptr;
-  float root_mass_ = 0.f;
+  nbody_hip_tree* handle() const { return reinterpret_cast<nbody_hip_tree*>(d_nodes_); }
 };
 
 class SpatialHashGrid {
@@ -177,8 +179,10 @@ private:
   int3 grid_dims_{0, 0, 0};
   int total_cells_ = 0;
   Vec3 bbox_min_, bbox_max_;
-  nbody_hip_grid* grid_ = nullptr;
-  size_t built_count_ = 0;
+  // the reference's data members only (spatial_hash_grid.hpp:36-52; sizeof == 96 under both
+  // header sets).  The engine's handle lives in the d_cell_start_ slot; the body count of the
+  // last build is asked from the handle.
+  nbody_hip_grid* handle() const { return reinterpret_cast<nbody_hip_grid*>(d_cell_start_); }
 };
 
 // ---- the strategy interface (the plugin boundary) ---------------------------------------------

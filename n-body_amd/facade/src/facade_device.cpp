@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <typeinfo>
 
 #include "nbody_facade.hpp"
 #include "nbody_hip.h"
@@ -30,6 +31,11 @@ nbody_particle_data* raw(ParticleData* p) { return reinterpret_cast<nbody_partic
 const nbody_particle_data* raw(const ParticleData* p) { return reinterpret_cast<const nbody_particle_data*>(p); }
 static_assert(sizeof(ParticleData) == sizeof(nbody_particle_data), "ParticleData layout");
 static_assert(sizeof(OctreeNode) == 76, "OctreeNode layout");
+// the reference's sizes (measured with its own headers; oracle/layout_probe.cpp compares every
+// member offset of both header sets)
+static_assert(sizeof(BarnesHutTree) == 96, "BarnesHutTree must keep the reference's layout");
+static_assert(sizeof(SpatialHashGrid) == 96, "SpatialHashGrid must keep the reference's layout");
+static_assert(sizeof(Integrator) == 24, "Integrator must keep the reference's layout");
 
 }  // namespace
 
@@ -162,29 +168,32 @@ Vec3 computeGravitationalForceCPU(const Vec3& p1, const Vec3& p2, float /*m1*/, 
 
 // ---- Barnes-Hut -----------------------------------------------------------------------------
 BarnesHutTree::BarnesHutTree(size_t max_particles) : max_particles_(max_particles) {
-  NBODY_CHECK(nbody_hip_tree_create(facadeContext(), max_particles, &tree_));
+  nbody_hip_tree* t = nullptr;
+  NBODY_CHECK(nbody_hip_tree_create(facadeContext(), max_particles, &t));
+  d_nodes_ = reinterpret_cast<OctreeNode*>(t);
 }
-BarnesHutTree::~BarnesHutTree() { nbody_hip_tree_destroy(tree_); }
+BarnesHutTree::~BarnesHutTree() { nbody_hip_tree_destroy(handle()); }
 void BarnesHutTree::build(const ParticleData* d) {
-  NBODY_CHECK(nbody_hip_tree_build(tree_, raw(d)));
+  NBODY_CHECK(nbody_hip_tree_build(handle(), raw(d)));
   int level_base[12];
-  NBODY_CHECK(nbody_hip_tree_stats(tree_, &node_count_, &root_mass_, nullptr, level_base));
+  NBODY_CHECK(nbody_hip_tree_stats(handle(), &node_count_, nullptr, nullptr, level_base));
   max_nodes_ = static_cast<size_t>(node_count_);
   max_depth_ = 0;
   for (int l = 1; l < 12; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
 }
 void BarnesHutTree::computeForces(ParticleData* d, float theta, float G, float eps) {
-  NBODY_CHECK(nbody_hip_tree_compute_forces(tree_, raw(d), theta, G, eps));
+  NBODY_CHECK(nbody_hip_tree_compute_forces(handle(), raw(d), theta, G, eps));
 }
 void BarnesHutTree::copyNodesToHost() {
   h_nodes_.resize(static_cast<size_t>(node_count_));
-  NBODY_CHECK(nbody_hip_tree_copy_nodes(tree_, h_nodes_.data(), node_count_, nullptr));
+  NBODY_CHECK(nbody_hip_tree_copy_nodes(handle(), h_nodes_.data(), node_count_, nullptr));
 }
 bool BarnesHutTree::verifyTreeStructure() const { return node_count_ > 0; }
 bool BarnesHutTree::verifyMassConservation(const ParticleData* h) const {
-  float total = 0.0f;
+  float total = 0.0f, root_mass = 0.0f;
   for (size_t i = 0; i < h->count; i++) total += h->mass[i];
-  return std::abs(total - root_mass_) < 0.001f * total;
+  if (nbody_hip_tree_stats(handle(), nullptr, &root_mass, nullptr, nullptr) != NBODY_HIP_OK) return false;
+  return std::abs(total - root_mass) < 0.001f * total;
 }
 
 BarnesHutCalculator::BarnesHutCalculator(float theta) : theta_(theta) {}
@@ -198,29 +207,32 @@ void BarnesHutCalculator::computeForces(ParticleData* d) {
 // ---- Spatial hash ----------------------------------------------------------------------------
 SpatialHashGrid::SpatialHashGrid(size_t max_particles, float cell_size)
     : max_particles_(max_particles), cell_size_(cell_size) {
-  NBODY_CHECK(nbody_hip_grid_create(facadeContext(), max_particles, cell_size, &grid_));
+  nbody_hip_grid* g = nullptr;
+  NBODY_CHECK(nbody_hip_grid_create(facadeContext(), max_particles, cell_size, &g));
+  d_cell_start_ = reinterpret_cast<int*>(g);
 }
-SpatialHashGrid::~SpatialHashGrid() { nbody_hip_grid_destroy(grid_); }
+SpatialHashGrid::~SpatialHashGrid() { nbody_hip_grid_destroy(handle()); }
 void SpatialHashGrid::build(const ParticleData* d) {
-  NBODY_CHECK(nbody_hip_grid_build(grid_, raw(d)));
+  NBODY_CHECK(nbody_hip_grid_build(handle(), raw(d)));
   int dims[3];
   float lo[3], hi[3];
-  NBODY_CHECK(nbody_hip_grid_info(grid_, dims, &total_cells_, lo, hi));
+  NBODY_CHECK(nbody_hip_grid_info(handle(), dims, &total_cells_, lo, hi));
   grid_dims_ = make_int3(dims[0], dims[1], dims[2]);
   bbox_min_ = Vec3(lo[0], lo[1], lo[2]);
   bbox_max_ = Vec3(hi[0], hi[1], hi[2]);
-  built_count_ = d->count;
 }
 void SpatialHashGrid::computeForces(ParticleData* d, float cutoff, float G, float eps) {
-  NBODY_CHECK(nbody_hip_grid_compute_forces(grid_, raw(d), cutoff, G, eps));
+  NBODY_CHECK(nbody_hip_grid_compute_forces(handle(), raw(d), cutoff, G, eps));
 }
 void SpatialHashGrid::copyCellDataToHost(std::vector<int>& cell_start, std::vector<int>& cell_end,
                                          std::vector<int>& particle_cells, std::vector<int>& sorted_indices) {
+  size_t built = 0;
+  NBODY_CHECK(nbody_hip_grid_count(handle(), &built));
   cell_start.resize(static_cast<size_t>(total_cells_));
   cell_end.resize(static_cast<size_t>(total_cells_));
-  particle_cells.resize(built_count_);
-  sorted_indices.resize(built_count_);
-  NBODY_CHECK(nbody_hip_grid_copy_cell_data(grid_, cell_start.data(), cell_end.data(), particle_cells.data(),
+  particle_cells.resize(built);
+  sorted_indices.resize(built);
+  NBODY_CHECK(nbody_hip_grid_copy_cell_data(handle(), cell_start.data(), cell_end.data(), particle_cells.data(),
                                             sorted_indices.data()));
 }
 int3 SpatialHashGrid::getCellIndex(float x, float y, float z, float cell_size) {
@@ -232,9 +244,11 @@ int SpatialHashGrid::hashCell(int3 c, int3 g) {
   return cx + cy * g.x + cz * g.x * g.y;
 }
 bool SpatialHashGrid::verifyCellAssignment(const ParticleData* h) const {
-  std::vector<int> pc(built_count_);
-  if (nbody_hip_grid_copy_cell_data(grid_, nullptr, nullptr, pc.data(), nullptr) != NBODY_HIP_OK) return false;
-  for (size_t i = 0; i < h->count && i < built_count_; i++) {
+  size_t built = 0;
+  if (nbody_hip_grid_count(handle(), &built) != NBODY_HIP_OK) return false;
+  std::vector<int> pc(built);
+  if (nbody_hip_grid_copy_cell_data(handle(), nullptr, nullptr, pc.data(), nullptr) != NBODY_HIP_OK) return false;
+  for (size_t i = 0; i < h->count && i < built; i++) {
     int3 c = getCellIndex(h->pos_x[i] - bbox_min_.x, h->pos_y[i] - bbox_min_.y, h->pos_z[i] - bbox_min_.z, cell_size_);
     c.x = std::max(0, std::min(c.x, grid_dims_.x - 1));
     c.y = std::max(0, std::min(c.y, grid_dims_.y - 1));
@@ -298,11 +312,17 @@ Integrator::Integrator(int block_size) : block_size_(block_size) {}
 Integrator::~Integrator() = default;
 void Integrator::ensureScratchBuffer(size_t) {}
 void Integrator::integrate(ParticleData* d, ForceCalculator* fc, float dt) {
-  if (fc->getMethod() == ForceMethod::DIRECT_N2 && dynamic_cast<DirectForceCalculator*>(fc)) {
-    // fused drift + force + kick (same result as the four calls below)
-    const float eps = fc->getSofteningParameter();
-    NBODY_CHECK(nbody_hip_integrate_direct(facadeContext(), raw(d), fc->getGravitationalConstant(), eps * eps, dt, 1));
-    return;
+  // The plugin contract is the virtual call (force_calculator.hpp:36-58, integrator.cu:234): the
+  // fused drift + force + kick launch sequence is taken only for EXACTLY the engine's own
+  // DirectForceCalculator (a subclass overriding computeForces goes through the virtual), and only
+  // with a block size computeForces itself would accept (otherwise the call below reports it).
+  if (typeid(*fc) == typeid(DirectForceCalculator)) {
+    const int bs = static_cast<DirectForceCalculator*>(fc)->getBlockSize();
+    if (bs >= 1 && bs <= 1024) {
+      const float eps = fc->getSofteningParameter();
+      NBODY_CHECK(nbody_hip_integrate_direct(facadeContext(), raw(d), fc->getGravitationalConstant(), eps * eps, dt, 1));
+      return;
+    }
   }
   NBODY_CHECK(nbody_hip_drift(facadeContext(), raw(d), dt));  // storeOldAccelerations + updatePositions, one pass
   fc->computeForces(d);

@@ -37,6 +37,25 @@ def test_particle_data_layout_matches_reference(nb):
         "acc_old_x", "acc_old_y", "acc_old_z", "mass"]
 
 
+def test_facade_classes_have_the_reference_layout():
+    """oracle/layout_probe.cpp compiled against the reference's headers and against the facade's
+    header (-fno-access-control): size, alignment and every data-member offset of all classes that
+    cross the C++ boundary are equal.  A caller built with the reference's headers puts
+    BarnesHutTree / SpatialHashGrid on its own stack (ref: tests/test_barnes_hut.cpp:29,54,118,
+    tests/test_spatial_hash.cpp:29,110) -- 96 bytes each."""
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    a, b = (os.path.join(ref, n) for n in ("layout_probe_ref", "layout_probe_facade"))
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref/layout_probe_* not built (needs /root/reference at build time)")
+    ta = subprocess.run([a], capture_output=True, text=True, check=True).stdout
+    tb = subprocess.run([b], capture_output=True, text=True, check=True).stdout
+    assert ta == tb
+    assert re.search(r"BarnesHutTree\s+size  96 align  8", ta)
+    assert re.search(r"SpatialHashGrid\s+size  96 align  8", ta)
+    assert len(ta.splitlines()) > 100
+
+
 def test_no_cpu_fallback(nb):
     import torch
     if torch.cuda.is_available():

@@ -62,6 +62,25 @@ def test_reference_example_force_methods(tmp_path):
         assert name in out
 
 
+# A caller compiled against the REFERENCE's headers that constructs BarnesHutTree / SpatialHashGrid
+# itself (as ref: tests/test_barnes_hut.cpp:29,54,118 and tests/test_spatial_hash.cpp:29,110 do) and
+# a user ForceCalculator subclass through Integrator::integrate.  The _asan build has the driver AND
+# the facade source instrumented: a facade method writing past the reference's 96 bytes aborts it.
+@pytest.mark.parametrize("exe", ["ref_tree_grid_driver", "ref_tree_grid_driver_asan"])
+def test_reference_header_caller_builds_tree_and_grid_itself(exe, tmp_path):
+    path = _need(exe)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = LIB + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    # the HIP runtime keeps process-lifetime allocations: leak reports are not what is tested
+    env["ASAN_OPTIONS"] = "detect_leaks=0:protect_shadow_gap=0:abort_on_error=0"
+    r = subprocess.run([path], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ALL PASSED" in r.stdout and "AddressSanitizer" not in r.stderr
+    for case in ("tree_build_and_mass", "tree_convergence", "grid_build_and_cells", "plugin_contract"):
+        assert f"PASS {case}" in r.stdout
+
+
 # the multi-GPU code paths (process group, RCCL all-gather, barrier, all-reduce) with ONE rank
 # under torch.distributed.run: everything except the cross-rank traffic itself
 @pytest.mark.parametrize("workload,n", [("direct", 65536), ("hash", 131072), ("bh", 100000)])

@@ -255,3 +255,52 @@ def test_shard_energies_sum_to_whole(nb, oracle, ctx, n, parts):
     assert abs(pac - pca) <= 1e-6 * abs(pac)   # fp32 per-pair terms round differently by direction
     s = host_state(ic)
     assert abs(pe_ref - oracle.potential_energy(s, 1.3, 0.02, 256, 2)) < 1e-5 * abs(pe_ref)
+
+
+# The plugin contract (ref: include/nbody/force_calculator.hpp:36-58, integrator.cu:234):
+# Integrator::integrate calls the calculator's VIRTUAL computeForces.  The fused launch sequence is
+# an optimisation for exactly the engine's own DirectForceCalculator and must not swallow a subclass.
+def test_integrate_calls_a_subclass_override(nb, ctx):
+    ic = nb.ic.plummer(512, seed=5)
+
+    class Counting(nb.DirectForceCalculator):
+        calls = 0
+
+        def computeForces(self, d_particles):
+            Counting.calls += 1
+            super().computeForces(d_particles)
+
+    class ZeroForce(nb.ForceCalculator):
+        calls = 0
+
+        def computeForces(self, d_particles):
+            ZeroForce.calls += 1
+
+        def getMethod(self):
+            return nb.ForceMethod.DIRECT_N2
+
+    def run(fc):
+        d, _ = to_device(nb, ic)
+        fc.setGravitationalConstant(1.0)
+        fc.setSofteningParameter(0.05)
+        fc.computeForces(d)
+        integ = nb.Integrator()
+        for _ in range(3):
+            integ.integrate(d, fc, 1e-3)
+        integ.integrate_steps(d, fc, 1e-3, 2)
+        return _state(d)
+
+    plain = run(nb.DirectForceCalculator())
+    Counting.calls = 0
+    sub = run(Counting())
+    assert Counting.calls == 1 + 3 + 2
+    for k in ("pos_x", "vel_y", "acc_z", "acc_old_x"):
+        assert np.array_equal(plain[k], sub[k]), k  # same arithmetic, fused or not
+    d, _ = to_device(nb, ic)
+    z = ZeroForce()
+    nb.Integrator().integrate(d, z, 1e-3)
+    assert ZeroForce.calls == 1
+    # an out-of-range block size is reported by the fused path's caller too (validateBlockSize range)
+    bad = nb.DirectForceCalculator(block_size=4096)
+    with pytest.raises(nb.ValidationException):
+        nb.Integrator().integrate(d, bad, 1e-3)
