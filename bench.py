@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane override")
     ap.add_argument("--splits", type=int, default=0, help="source splits override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the Barnes-Hut / spatial-hash / general-mass objects appended to the default run")
     ap.add_argument("--workload", choices=["direct", "hash", "bh"], default="direct",
                     help="direct = the headline metric (default); hash = BASELINE config 5 (N=4,194,304 "
                          "uniform box, spatial hash, z-slab shards + halo exchange); bh = config 4 "
@@ -139,12 +141,16 @@ def read_pmc_traffic():
         return None
 
 
-def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
+def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch, workload=None, n_bodies=None,
+                       steps=None, warmup=None):
     """BASELINE configs 4 and 5: steps/s of a full Velocity-Verlet step (not the headline metric)."""
     from nbody_amd.distributed import HipBackend, ShardedHashSystem
     dt = a.dt
-    if a.workload == "hash":
-        n = a.n if a.n != (1 << 20) else 4194304
+    workload = workload or a.workload
+    steps = steps or a.steps
+    warmup = a.warmup if warmup is None else warmup
+    if workload == "hash":
+        n = n_bodies or (a.n if a.n != (1 << 20) else 4194304)
         half = 0.5 * (n / 16.0) ** (1.0 / 3.0)  # 16 bodies per unit volume (SURVEY 8d config 5)
         ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
         cell, cutoff, eps = 1.0, 1.0, 0.01
@@ -162,7 +168,7 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
             path = "ParticleSystem(SPATIAL_HASH)"
         name = f"uniform_box_N{n}_spatial_hash_cell1_cutoff1_velocity_verlet"
     else:
-        n = a.n
+        n = n_bodies or a.n
         ic = nb.ic.two_galaxies(n, seed=42)
         ic["mass"] = (ic["mass"] / np.float32(n)).astype(np.float32)
         if sharded:
@@ -184,11 +190,11 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -198,22 +204,67 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch):
         elapsed = float(t.item())
     if rank != 0:
         return None
-    out = {"metric": "steps_per_s", "value": a.steps / elapsed, "unit": "steps/s", "n_gpus": world,
-           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+    out = {"metric": "steps_per_s", "value": steps / elapsed, "unit": "steps/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic", "config": {"workload": name, "bodies": n, "dt": dt, "path": path}}
     if not sharded:
-        out["roofline"] = other_roofline(a, nb, ps, torch)
+        out["roofline"] = other_roofline(a, nb, ps, torch, workload)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = other_cpu_baseline(workload, ic, a.cpu_seconds / 2.0)
     return out
 
 
-def other_roofline(a, nb, ps, torch):
+def other_cpu_baseline(workload, ic, seconds):
+    """The oracle's Barnes-Hut / spatial hash (kind "port") on this box's cores: the
+    serial build once + the walk of a bounded target sample, extrapolated to one force evaluation
+    over all bodies (the O(N) Velocity-Verlet passes are not included: they favour the CPU figure)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind
+    lib = oracle_bind.load(fast=True)
+    cores = min(lib.num_threads(), cpu_share())
+    lib.L.oracle_set_num_threads(cores)
+    x, y, z, m = (np.ascontiguousarray(ic[k], dtype=np.float32) for k in ("pos_x", "pos_y", "pos_z", "mass"))
+    n = x.size
+    if workload == "bh":
+        eps2, theta = float(np.float32(0.1) * np.float32(0.1)), 0.5
+
+        def run(t):
+            idx = np.linspace(0, n - 1, t).astype(np.int64)
+            t0 = time.perf_counter()
+            lib.barnes_hut_forces(x, y, z, m, idx, 1.0, eps2, theta)
+            return time.perf_counter() - t0
+        what = "oracle octree (serial sort + build) + theta-0.5 walk"
+    else:
+        eps2 = float(np.float32(0.01) * np.float32(0.01))
+        lo, _, dims = lib.hash_grid(x, y, z, 1.0)
+
+        def run(t):  # targets = the first t bodies (the uniform box has no index/position correlation)
+            t0 = time.perf_counter()
+            lib.spatial_hash_forces_grid(x, y, z, m, t, 1.0, eps2, 1.0, 1.0, lo, dims)
+            return time.perf_counter() - t0
+        what = "oracle grid (serial counting sort) + 27-cell cutoff sums"
+    t_small = cores
+    dt_small = run(t_small)                      # ~ the build alone
+    t_probe = cores * 256
+    dt_probe = run(t_probe)
+    per_target = max(dt_probe - dt_small, 1e-9) / (t_probe - t_small)
+    targets = int(min(n, max(t_probe, (seconds - dt_small) / per_target)))
+    dt_big = run(targets)
+    per_target = max(dt_big - dt_small, 1e-9) / (targets - t_small)
+    t_eval = dt_small + per_target * n
+    return {"value": 1.0 / t_eval, "unit": "force-evaluations/s", "cores": cores, "kind": "port",
+            "sample": f"{what}: build {dt_small:.2f} s + {targets} of {n} targets in {dt_big - dt_small:.2f} s, "
+                      f"extrapolated to all {n} targets = {t_eval:.1f} s per force evaluation; OpenMP over targets"}
+
+
+def other_roofline(a, nb, ps, torch, workload):
     """SURVEY 8d figures for the force kernel of configs 4 / 5, timed alone with events on the
     stream it runs on (the null stream = torch's current stream)."""
     fc, d = ps.force_calculator_, ps.d_particles_
     iters = max(1, a.kernel_iters)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if a.workload == "bh":
+    if workload == "bh":
         tree = fc.getTree()
         tree.countVisits(True)
         run = lambda: tree.computeForces(d, fc.theta_, fc.G_, fc.softening_eps_)  # noqa: E731
@@ -228,7 +279,7 @@ def other_roofline(a, nb, ps, torch):
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / iters
-    if a.workload == "bh":
+    if workload == "bh":
         st = tree.stats()  # node records fetched by the last walk, summed over waves
         visits = int(st["nodes_visited"])
         nbytes = 32.0 * visits + 16.0 * d.count  # 32-byte record per visit + the body itself
@@ -409,6 +460,33 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, eps, a.cpu_seconds)
+        if world == 1 and not a.no_extra and n >= 12288 and a.variant in (-1, 3):
+            # the same bodies with masses spread over +-25 %: the general-mass instantiation
+            # <R,false,false> (two more multiplies per pair than the equal-mass one above)
+            rng = np.random.default_rng(7)
+            pg = p.clone()
+            pg[:, 3] *= torch.from_numpy((0.75 + 0.5 * rng.random(n)).astype(np.float32)).cuda()
+            ms_g = nb.time_direct_packed(ctx, pg, pg, G, eps2, a.kernel_iters)
+            ach_g = FLOP_PER_PAIR * float(n) * n / (ms_g * 1e-3) / 1e12
+            out["roofline"]["general_mass"] = {
+                "kernel": kname.replace(",true>", ",false>"), "launch_ms": ms_g, "achieved": ach_g,
+                "frac": ach_g / PEAK_FP32_VALU_TFLOPS, "pair_interactions_per_s_kernel": float(n) * n / (ms_g * 1e-3),
+                "note": "same positions, masses multiplied by U[0.75, 1.25)"}
+            del pg
+        del p
+    if not sharded and not a.no_extra and a.n == (1 << 20):
+        # BASELINE configs 4 and 5 in the driver-run record (outside the Direct timed region):
+        # what `--workload bh` / `--workload hash` print, each with its roofline and CPU baseline
+        torch.cuda.empty_cache()
+        extra = {}
+        for key, wl, nn in (("barnes_hut", "bh", 1 << 20), ("spatial_hash", "hash", 4194304)):
+            try:
+                extra[key] = run_other_workload(a, nb, ctx, world, rank, False, dist, torch, workload=wl,
+                                                n_bodies=nn, steps=20, warmup=3)
+            except Exception as e:  # the headline line must survive a failure here
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+        if out is not None:
+            out["extra"] = extra
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,4 +17,4 @@ from .api import (BarnesHutCalculator, BarnesHutTree, Context, StepGraph, Direct
                   time_direct_packed)
 from .system import (MAX_PARTICLE_COUNT, NBODY_MAGIC, NBODY_VERSION, ParticleSystem,  # noqa: F401,E402
                      Serializer, SimulationState)
-from . import cli, observability  # noqa: F401,E402
+from . import cli, observability  # noqa: F401,E402  (benchmarks: `python -m nbody_amd.benchmarks`, imported on demand)

@@ -2,6 +2,7 @@
 record JSON (tests/test_performance_observability.cpp:7-24) and the phase profiler (:26-41)."""
 import json
 import os
+import re
 import subprocess
 import time
 
@@ -173,3 +174,84 @@ def test_benchmark_records_equal_reference_serializer(nb):
     c = ob.BenchmarkRunRecord(benchmark_name="empty", force_method=nb.ForceMethod.SPATIAL_HASH)
     assert ob.serializeBenchmarkRunRecords([a, b, c]) == out[0]
     assert ob.serializeBenchmarkRunRecord(a) == out[1]
+
+
+# f2: the named benchmark runner pinned to the reference's OWN runner (oracle/_ref/nbody_benchmarks =
+# benchmarks/benchmark_main.cpp compiled as the reference's headless CI does, NBODY_WITH_CUDA=0, so
+# only serialization.round_trip is compiled in): option handling, error texts, the listing and the
+# serialization record.  The four device benchmarks run on the GPU (tests/test_particle_system_gpu.py).
+REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "nbody_benchmarks")
+BENCH_ARGV = [
+    ["--list"], ["--help"], ["-h"], ["--bogus"], ["--particle-count", "abc"], ["--particle-count"],
+    ["--iterations", "0"], ["--iterations"], ["--benchmark", "nope"], ["--benchmark"],
+    ["--particle-count", "99999999999999999999999"], ["--iterations", "x3"], ["extra"],
+    ["--benchmark", "serialization.round_trip", "--particle-count", "257", "--iterations", "3"],
+    ["--benchmark", "serialization.round_trip", "--particle-count", " 12abc", "--iterations", "+2"],
+    ["--benchmark", "serialization.round_trip", "--particle-count", "0", "--iterations", "1"],
+]
+
+
+def _run_mine(args, env=None):
+    import io
+    from nbody_amd import benchmarks
+    out, err = io.StringIO(), io.StringIO()
+    rc = benchmarks.main(["nbody_benchmarks"] + args, out=out, err=err)
+    return rc, out.getvalue(), err.getvalue()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BENCH), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("args", BENCH_ARGV, ids=lambda a: " ".join(a))
+def test_benchmark_runner_equals_reference_runner(nb, args, monkeypatch):
+    import json
+    monkeypatch.delenv("NBODY_BENCHMARK_PARTICLES", raising=False)
+    monkeypatch.delenv("NBODY_BENCHMARK_ITERATIONS", raising=False)
+    monkeypatch.delenv("NBODY_ENABLE_PROFILING", raising=False)
+    r = subprocess.run([REF_BENCH] + args, capture_output=True, text=True, timeout=60)
+    rc, out, err = _run_mine(args)
+    assert rc == r.returncode
+    assert err == r.stderr
+    if args[0] in ("--list", "--help", "-h"):
+        # the reference built without its GPU code lists one benchmark; its listing code prints the
+        # other four as "  - name (CUDA): description" when they are compiled in (benchmark_main.cpp:226-236,246-250)
+        mine, ref = out.splitlines(), r.stdout.splitlines()
+        assert mine[:5] == ref[:5]
+        assert mine[5:] == ["  - force.direct_n2 (CUDA): Direct N^2 force calculation",
+                            "  - force.barnes_hut (CUDA): Barnes-Hut force calculation",
+                            "  - force.spatial_hash (CUDA): Spatial hash force calculation",
+                            "  - integration.velocity_verlet (CUDA): Velocity Verlet integration step"]
+        return
+    if rc != 0:
+        assert out == r.stdout == ""
+        return
+    a, b = json.loads(out), json.loads(r.stdout)
+    assert list(a) == list(b) == ["benchmarks"] and len(a["benchmarks"]) == len(b["benchmarks"]) == 1
+    ra, rb = a["benchmarks"][0], b["benchmarks"][0]
+    assert list(ra) == list(rb)  # same fields, same order
+    for k in ("benchmark_name", "force_method", "particle_count", "iterations", "parameters", "phase_timings"):
+        assert ra[k] == rb[k], k
+    assert list(ra["metrics"]) == list(rb["metrics"]) == ["bytes_per_iteration", "wall_time_ms"]
+    assert ra["metrics"]["bytes_per_iteration"] == rb["metrics"]["bytes_per_iteration"]
+    # byte-identical once the (machine-dependent) time is masked
+    mask = lambda s: re.sub(r'"wall_time_ms":[^,}]+', '"wall_time_ms":T', s)  # noqa: E731
+    assert mask(out) == mask(r.stdout)
+
+
+def test_benchmark_runner_state_and_output_file(nb, tmp_path, monkeypatch):
+    import json
+    from nbody_amd import benchmarks
+    st = benchmarks.makeState(200)  # benchmark_main.cpp:46-53, fp32 products
+    assert st.pos_x[98] == np.float32(1) * np.float32(0.01) and st.pos_y[30] == np.float32(1) * np.float32(0.02)
+    assert st.pos_z[12] == np.float32(84 % 83) * np.float32(0.03) and st.vel_z[16] == np.float32(0.003) * np.float32(16)
+    assert st.mass.dtype == np.float32 and np.all(st.mass == 1)
+    monkeypatch.setenv("NBODY_BENCHMARK_PARTICLES", "64")   # scripts/benchmark.sh:12-13
+    monkeypatch.setenv("NBODY_BENCHMARK_ITERATIONS", "2")
+    monkeypatch.setenv("NBODY_ENABLE_PROFILING", "1")
+    path = tmp_path / "sub.json"
+    rc, out, err = _run_mine(["--benchmark", "serialization.round_trip", "--output", str(path)])
+    assert rc == 0 and err == ""
+    rec = json.loads(out)["benchmarks"][0]
+    assert rec["particle_count"] == 64 and rec["iterations"] == 2
+    assert rec["metrics"]["bytes_per_iteration"] == 56 + 7 * 4 * 64
+    assert [p["name"] for p in rec["phase_timings"]] == ["serialization.save", "serialization.load"]
+    assert all(p["samples"] == 2 for p in rec["phase_timings"])
+    assert json.loads(path.read_text()) == json.loads(out)

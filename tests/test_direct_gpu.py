@@ -242,6 +242,33 @@ def test_full_size_properties(nb, oracle, ctx):
     assert rel_err(ah[idx], ref).max() < TOL
 
 
+# The headline configuration itself (N = 1,048,576, default tuning: direct_sym_kernel<16,...> with the
+# fp64 I-side sums in LDS) against the oracle on 2,048+ bodies -- 1,536 at random, the 256 innermost
+# and the 256 outermost of the Plummer sphere -- for the equal-mass body set of the bench AND a
+# general-mass one (the <16,false,false> instantiation).  Tolerance: north_star's 1e-5 per body.
+@pytest.mark.parametrize("masses", ["equal", "general"])
+def test_headline_size_vs_oracle(nb, oracle, ctx, masses):
+    n = 1 << 20
+    ic = nb.ic.plummer(n, seed=42)
+    if masses == "general":
+        ic["mass"] = (ic["mass"] * np.random.default_rng(7).uniform(0.75, 1.25, n)).astype(np.float32)
+    p = packed(ic)
+    eps2 = float(np.float32(1e-3) * np.float32(1e-3))
+    a = nb.direct_forces_packed(ctx, p, p, 1.0, eps2).cpu().numpy()[:, :3]
+    rng = np.random.default_rng(2)
+    r = np.sqrt(ic["pos_x"].astype(np.float64) ** 2 + ic["pos_y"].astype(np.float64) ** 2
+                + ic["pos_z"].astype(np.float64) ** 2)
+    order = np.argsort(r)
+    idx = np.unique(np.concatenate([rng.choice(n, 1536, replace=False), order[:256], order[-256:]]))
+    assert idx.size >= 2000
+    ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
+                                                1.0, eps2, 1), 1)
+    err = rel_err(a[idx], ref)
+    print(f"N = {n}, {masses} masses, {idx.size} oracle bodies: max rel err {err.max():.3e}, "
+          f"rms {np.sqrt((err ** 2).mean()):.3e}")
+    assert err.max() < 1e-5, f"max per-body relative error {err.max():.3e} over {idx.size} bodies ({masses} masses)"
+
+
 # the symmetric (action = -reaction) kernel at sizes where it is the default, all register
 # blockings, ragged N (padding inside the last superblock), even and odd superblock counts
 @pytest.mark.parametrize("equal_mass", [True, False])

@@ -156,3 +156,42 @@ def test_create_destroy_cycles_release_memory(nb, ctx):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, (free0, free1)  # no growth beyond allocator noise
+
+
+# ref: benchmarks/benchmark_main.cpp:95-236 -- the five named benchmarks at the defaults of
+# scripts/benchmark.sh (4,096 particles, 5 iterations), records shaped as the reference's
+def test_named_benchmark_runner_all_five(nb, ctx, tmp_path, monkeypatch):
+    import io
+    import json
+    from nbody_amd import benchmarks
+    monkeypatch.setenv("NBODY_ENABLE_PROFILING", "1")
+    path = tmp_path / "benchmark-results.json"
+    out, err = io.StringIO(), io.StringIO()
+    assert benchmarks.main(["nbody_benchmarks", "--output", str(path)], out=out, err=err) == 0, err.getvalue()
+    recs = json.loads(path.read_text())["benchmarks"]
+    assert json.loads(out.getvalue())["benchmarks"] == recs
+    assert [r["benchmark_name"] for r in recs] == ["serialization.round_trip", "force.direct_n2", "force.barnes_hut",
+                                                   "force.spatial_hash", "integration.velocity_verlet"]
+    assert [r["force_method"] for r in recs] == ["direct_n2", "direct_n2", "barnes_hut", "spatial_hash", "direct_n2"]
+    by = {r["benchmark_name"]: r for r in recs}
+    for r in recs:
+        assert r["particle_count"] == 4096 and r["iterations"] == 5 and r["metrics"]["wall_time_ms"] > 0
+        assert r["parameters"]["particle_count"] == 4096
+    # parameters per benchmark as the reference records them (:111-118, :146-148, :184-185)
+    assert set(by["force.direct_n2"]["parameters"]) == {"particle_count", "cuda_block_size"}
+    assert set(by["force.barnes_hut"]["parameters"]) == {"particle_count", "theta"}
+    assert by["force.barnes_hut"]["parameters"]["theta"] == pytest.approx(0.5)
+    assert set(by["force.spatial_hash"]["parameters"]) == {"particle_count", "cuda_block_size", "cell_size", "cutoff_radius"}
+    assert set(by["integration.velocity_verlet"]["parameters"]) == {"particle_count", "dt", "cuda_block_size"}
+    # phases under the reference's names; Barnes-Hut copies them into metrics (:203-209)
+    assert [p["name"] for p in by["force.direct_n2"]["phase_timings"]] == ["force.direct_n2"]
+    assert by["force.barnes_hut"]["metrics"]["barnes_hut.build_ms"] > 0
+    assert [p["samples"] for p in by["integration.velocity_verlet"]["phase_timings"]] == [5]
+    # device-synchronised timing: 4096^2 pairs cannot take less than a microsecond
+    assert 1e6 < by["force.direct_n2"]["metrics"]["pair_interactions_per_s"] < 1e14
+    # one benchmark by name
+    out2 = io.StringIO()
+    assert benchmarks.main(["x", "--benchmark", "force.spatial_hash", "--particle-count", "1000", "--iterations", "2"],
+                           out=out2, err=err) == 0
+    only = json.loads(out2.getvalue())["benchmarks"]
+    assert len(only) == 1 and only[0]["particle_count"] == 1000
