@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (FIELDS, ParticleDataStruct, ValidationException, check)
+from ._lib import (FIELDS, ParticleDataStruct, StateException, ValidationException, check)
 
 
 class ForceMethod(enum.IntEnum):  # types.hpp:66-70
@@ -573,9 +573,10 @@ class SpatialHashCalculator(ForceCalculator):
         return ForceMethod.SPATIAL_HASH
 
     def setCellSize(self, size):
+        # force_calculator.hpp:199: a plain store.  A grid that already exists was constructed with
+        # the earlier size and keeps it (the reference never re-creates or re-sizes its grid,
+        # force_spatial_hash.cu:372-374); the new value is used by the next grid this calculator creates.
         self.cell_size_ = float(size)
-        if self.grid_ is not None:
-            self.grid_.setCellSize(size)
 
     def setCutoffRadius(self, radius):
         self.cutoff_radius_ = float(radius)
@@ -773,8 +774,8 @@ class Integrator:
             return
         if graph is None:
             graph = False
-        if graph and isinstance(force_calc, SpatialHashCalculator):
-            graph = False
+        if graph and (isinstance(force_calc, SpatialHashCalculator) or force_calc.ctx is not self.ctx):
+            graph = False  # not capturable / the step's launches would be split over two contexts
         if not graph:
             if self._fusable(force_calc):
                 s = d_particles.struct()
@@ -785,17 +786,32 @@ class Integrator:
                 for _ in range(steps):
                     self.integrate(d_particles, force_calc, dt)
             return
-        key = (d_particles.pos_x.data_ptr(), d_particles.count, float(dt), id(force_calc), force_calc._graph_key())
-        if getattr(self, "_graph_for", None) != key:
+        ctx = force_calc.ctx  # the calculator's context is the one the step's launches go to
+        key = (d_particles.pos_x.data_ptr(), d_particles.count, float(dt), id(force_calc), force_calc._graph_key(),
+               id(ctx))
+
+        def record(steps):
             self._graph, self._graph_for = None, None
             self.integrate(d_particles, force_calc, dt)  # eager: allocations happen here
             steps -= 1
+            if steps > 0:
+                with ctx.capture() as rec:
+                    self.integrate(d_particles, force_calc, dt)
+                self._graph, self._graph_for = rec.graph, key
+            return steps
+
+        if getattr(self, "_graph_for", None) != key:
+            steps = record(steps)
             if steps == 0:
                 return
-            with self.ctx.capture() as rec:
-                self.integrate(d_particles, force_calc, dt)
-            self._graph, self._graph_for = rec.graph, key
-        self._graph.launch(steps)
+        try:
+            self._graph.launch(steps)
+        except StateException:
+            # stale recording: another system grew a workspace of the shared context, or the tree was
+            # re-sized, since it was made (nbody_hip_graph_launch checks the generation) -> record again
+            steps = record(steps)
+            if steps:
+                self._graph.launch(steps)
 
     def updatePositions(self, d_particles, dt):
         s = d_particles.struct()

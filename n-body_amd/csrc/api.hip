@@ -43,6 +43,7 @@ int Workspace::reserve(size_t want) {
   }
   ptr = p;
   bytes = cap;
+  generation++;
   return NBODY_HIP_OK;
 }
 
@@ -50,6 +51,7 @@ void Workspace::release() {
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr;
   bytes = 0;
+  generation++;
 }
 
 }  // namespace nbh
@@ -129,6 +131,7 @@ struct nbody_hip_graph {
   nbody_hip_ctx* ctx = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  unsigned long long generation = 0;  // ctx->generation() when it was recorded
 };
 
 extern "C" int nbody_hip_capture_begin(nbody_hip_ctx* ctx) {
@@ -163,6 +166,7 @@ extern "C" int nbody_hip_capture_end(nbody_hip_ctx* ctx, nbody_hip_graph** out) 
   nbody_hip_graph* g = new nbody_hip_graph();
   g->ctx = ctx;
   g->graph = graph;
+  g->generation = ctx->generation();
   const hipError_t ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
   if (ei != hipSuccess) {
     (void)hipGraphDestroy(graph);
@@ -176,6 +180,11 @@ extern "C" int nbody_hip_capture_end(nbody_hip_ctx* ctx, nbody_hip_graph** out) 
 extern "C" int nbody_hip_graph_launch(nbody_hip_graph* g, int times) {
   if (!g || !g->exec) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null graph");
   if (g->ctx->capturing) return NBH_FAIL(NBODY_HIP_ERR_STATE, "graph launch inside a capture");
+  // the recording holds raw pointers into the context's workspaces and into the tree it was made
+  // with: if any of them was re-allocated or freed since, replaying would touch freed memory
+  if (g->generation != g->ctx->generation())
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "step graph is stale: device buffers of its context were re-allocated "
+                    "after it was recorded (record it again)");
   NBH_HIP(hipSetDevice(g->ctx->device));
   for (int i = 0; i < times; i++) NBH_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
   return NBODY_HIP_OK;

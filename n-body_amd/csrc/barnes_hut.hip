@@ -681,6 +681,7 @@ extern "C" int nbody_hip_tree_destroy(nbody_hip_tree* g) {
   if (!g) return NBODY_HIP_OK;
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->stream);
+  g->ctx->alloc_generation++;  // a step graph recorded with this tree is stale now
   tree_release(g);
   return NBODY_HIP_OK;
 }
@@ -696,6 +697,7 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
   g->max_depth = max_depth;
   g->leaf_max = leaf_max;
   g->built_count = 0;
+  g->ctx->alloc_generation++;  // the node arrays are replaced: recorded step graphs are stale
   return tree_alloc_nodes(g);
 }
 

@@ -57,6 +57,7 @@ int fail(nbody_hip_status code, const char* file, int line, const char* fmt, ...
 struct Workspace {
   void* ptr = nullptr;
   size_t bytes = 0;
+  unsigned long long generation = 0;  // bumped whenever `ptr` is replaced (step graphs bake it in)
   int reserve(size_t want);  // grows (never shrinks); returns status
   void release();
 };
@@ -77,6 +78,12 @@ struct nbody_hip_ctx {
   mutable bool capture_failed = false;           // a non-capturable call was made while recording
   // tuning overrides (variant -1 / others 0 = automatic)
   int tune_variant = -1, tune_tpl = 0, tune_splits = 0;
+  // bumped when a tree / grid of this context re-sizes or frees device arrays a recorded step graph
+  // may point into; together with the workspaces' generations it dates a recording
+  unsigned long long alloc_generation = 0;
+  unsigned long long generation() const {
+    return posm.generation + partial.generation + reduce.generation + alloc_generation;
+  }
 };
 
 namespace nbh {

@@ -132,6 +132,19 @@ struct GridInfo {
   long long total;
 };
 
+// cells per axis (force_spatial_hash.cu:244-246) with the int conversion guarded: NaN / inf / huge
+// extents become 2^30 cells, which the "grid too large" check then rejects
+__host__ __device__ inline int grid_axis_cells(float lo, float hi, float cell) {
+  const float cells = ceilf((hi - lo) / cell);
+  return (cells < 1.0e9f && cells >= 0.0f) ? (int)cells + 1 : 0x40000000;
+}
+// running product of the axis sizes, SATURATING at 2^50 (three axes of 2^30 would wrap a 64-bit
+// product to 0 and slip under the 1e8 limit)
+__host__ __device__ inline long long grid_cells_times(long long total, int d) {
+  const long long cap = 0x4000000000000LL;
+  return (d <= 0 || total > cap / d) ? cap : total * d;
+}
+
 // decode, pad by `pad` (0.001 for the hash grid, force_spatial_hash.cu:225-231), size the grid
 __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cell, float pad,
                                  GridInfo* __restrict__ info) {
@@ -142,12 +155,9 @@ __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cel
     const float hi = ordered_to_float(enc[3 + a]) + pad;
     info->bmin[a] = lo;
     info->bmax[a] = hi;
-    const float cells = ceilf((hi - lo) / cell);
-    // guard the int conversion: anything beyond 2^30 is reported as "too large" by the host
-    const int d = (cells < 1.0e9f && cells >= 0.0f) ? (int)cells + 1 : 0x40000000;
+    const int d = grid_axis_cells(lo, hi, cell);
     info->dims[a] = d;
-    total *= d;
-    if (total > 0x4000000000000LL) total = 0x4000000000000LL;
+    total = grid_cells_times(total, d);
   }
   info->total = total;
 }
@@ -469,10 +479,8 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     for (int a = 0; a < 3; a++) {
       gi.bmin[a] = bounds[a];
       gi.bmax[a] = bounds[3 + a];
-      const float cells = ceilf((bounds[3 + a] - bounds[a]) / g->cell_size);  // :244-246
-      gi.dims[a] = (cells < 1.0e9f && cells >= 0.0f) ? (int)cells + 1 : 0x40000000;
-      total *= gi.dims[a];
-      if (total > 0x4000000000000LL) total = 0x4000000000000LL;
+      gi.dims[a] = grid_axis_cells(bounds[a], bounds[3 + a], g->cell_size);  // :244-246
+      total = grid_cells_times(total, gi.dims[a]);
     }
     gi.total = total;
     g->info = gi;

@@ -304,3 +304,48 @@ def test_integrate_calls_a_subclass_override(nb, ctx):
     bad = nb.DirectForceCalculator(block_size=4096)
     with pytest.raises(nb.ValidationException):
         nb.Integrator().integrate(d, bad, 1e-3)
+
+
+# A recorded step graph holds raw pointers into the context's workspaces (shared by every system on
+# the device) and into its tree.  When a LARGER system later grows a workspace, or the tree is re-sized,
+# the old buffers are freed: replaying must be refused (NBODY_HIP_ERR_STATE), not touch freed memory;
+# Integrator.integrate_steps records again by itself.
+def test_stale_step_graph_is_refused_and_rerecorded(nb, ctx):
+    small = nb.ic.plummer(3000, seed=1)
+    d, _ = to_device(nb, small)
+    fc = nb.DirectForceCalculator()
+    fc.setSofteningParameter(0.05)
+    integ = nb.Integrator()
+    fc.computeForces(d)
+    integ.integrate_steps(d, fc, 1e-3, 3, graph=True)
+    old = integ._graph
+    assert old is not None
+    # a system 100x larger on the same (default) context re-allocates posm / partial
+    big = nb.ic.plummer(300000, seed=2)
+    d2, _ = to_device(nb, big)
+    fc2 = nb.DirectForceCalculator()
+    fc2.setSofteningParameter(0.05)
+    fc2.computeForces(d2)
+    ctx.synchronize()
+    with pytest.raises(nb.StateException, match="stale"):
+        old.launch(1)
+    # the high-level call recovers: same trajectory as an eager run from the same state
+    ref, _ = to_device(nb, {k: getattr(d, k).cpu().numpy() for k in (
+        "pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")})
+    for k in ("acc_x", "acc_y", "acc_z"):
+        getattr(ref, k).copy_(getattr(d, k))
+    integ.integrate_steps(d, fc, 1e-3, 3, graph=True)
+    assert integ._graph is not old
+    nb.Integrator().integrate_steps(ref, fc, 1e-3, 3, graph=False)
+    for k in ("pos_x", "vel_y", "acc_z"):
+        assert torch.equal(getattr(d, k), getattr(ref, k)), k
+    # a tree re-sized after the recording
+    bh = nb.BarnesHutCalculator(0.5)
+    bh.setSofteningParameter(0.05)
+    bh.computeForces(d)
+    integ2 = nb.Integrator()
+    integ2.integrate_steps(d, bh, 1e-3, 2, graph=True)
+    g = integ2._graph
+    bh.getTree().setParams(8, 4)
+    with pytest.raises(nb.StateException, match="stale"):
+        g.launch(1)

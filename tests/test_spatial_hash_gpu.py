@@ -253,3 +253,27 @@ def test_golden_uniform_4096(nb, ctx):
         assert list(calc.getGrid().getGridDims()) == list(g["dims"])
     cs, ce, pc, si = calc.getGrid().copyCellDataToHost()
     assert np.array_equal(pc, g["cell_of"])   # every body in the cell the oracle puts it in
+
+
+# A blown-up system: bodies at +-inf / NaN on all three axes.  Every axis saturates at 2^30 cells; the
+# running product must saturate too (2^30 * 2^30 * 2^30 wraps a 64-bit product to 0, which would slip
+# under the 1e8-cell limit): "Spatial hash grid too large" (ref: force_spatial_hash.cu:252-254).
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan, 3.0e38])
+def test_grid_too_large_with_non_finite_positions(nb, ctx, bad):
+    ic = nb.ic.uniform_box(1000, seed=9, lo=-4.0, hi=4.0)
+    for k in ("pos_x", "pos_y", "pos_z"):
+        ic[k][7] = np.float32(bad)
+        ic[k][11] = np.float32(-bad)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(1.0, 1.0)
+    with pytest.raises(nb.NBodyError, match="too large"):
+        calc.computeForces(d)
+    # explicit-bounds form used by the sharded path
+    import ctypes as C
+    from gpu_util import packed
+    from nbody_amd._lib import check
+    grid = nb.SpatialHashGrid(1000, 1e-3)
+    p = packed(ic)
+    bounds = (C.c_float * 6)(-3e38, -3e38, -3e38, 3e38, 3e38, 3e38)
+    with pytest.raises(nb.NBodyError, match="too large"):
+        check(ctx._lib.nbody_hip_grid_build_packed(grid._h, p.data_ptr(), 1000, bounds))
