@@ -258,6 +258,11 @@ def other_cpu_baseline(workload, ic, seconds):
                       f"extrapolated to all {n} targets = {t_eval:.1f} s per force evaluation; OpenMP over targets"}
 
 
+def n_cells_dense(cnt):
+    """the grid picks the wave-per-cell kernel with two bodies per lane from 8 bodies per cell"""
+    return cnt.sum() / max(cnt.size, 1) >= 8.0
+
+
 def other_roofline(a, nb, ps, torch, workload):
     """SURVEY 8d figures for the force kernel of configs 4 / 5, timed alone with events on the
     stream it runs on (the null stream = torch's current stream)."""
@@ -299,7 +304,8 @@ def other_roofline(a, nb, ps, torch, workload):
                 nb27 += pad[dz:dz + gz, dy:dy + gy, dx:dx + gx]
     pairs = float((cnt * nb27).sum())  # candidate pairs: every body against the bodies of its 27 cells
     flops = 20.0 * pairs
-    return {"kernel": "hash_force_kernel", "bound": "valu", "achieved": flops / t / 1e12, "peak": 157.3,
+    return {"kernel": "hash_cell_force_kernel<false,2> (wave per cell)" if n_cells_dense(cnt) else "hash_force_kernel",
+            "bound": "valu", "achieved": flops / t / 1e12, "peak": 157.3,
             "unit": "TFLOP/s", "frac": flops / t / 157.3e12, "traffic": None, "avg_kernel_ms": t * 1e3,
             "candidate_pairs_per_s": pairs / t, "gather_bytes_per_s": 16.0 * pairs / t,
             "note": "20 flop per candidate pair (distance + cutoff test + force); 16 B per candidate pair is the "

@@ -220,6 +220,11 @@ NBODY_HIP_API int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles
 NBODY_HIP_API int nbody_hip_grid_destroy(nbody_hip_grid* grid);
 /* ref: SpatialHashCalculator::setCellSize (force_calculator.hpp:199): takes effect at the next build */
 NBODY_HIP_API int nbody_hip_grid_set_cell_size(nbody_hip_grid* grid, float cell_size);
+/* Tuning hook for measurements: force kernel 0 = automatic, 1 = cell-run kernel (one workgroup per
+ * run of cells along x, binary-searched ranges; the only one for very sparse grids), 2 / 3 / 4 = wave-per-
+ * cell kernel with 1 / 2 / 4 bodies per lane (needs a grid of at most ~4 cells per body).  All give the
+ * reference's 27-cell result; they differ by fp rounding of the summation order only. */
+NBODY_HIP_API int nbody_hip_grid_tuning(nbody_hip_grid* grid, int kernel);
 /* ref: SpatialHashGrid::build :235-303 -- bounding box (padded 0.001), grid dims
  * ceil(extent/cell)+1, cell id per body, bodies ordered by cell.  More than 1e8 cells ->
  * NBODY_HIP_ERR_RESOURCE ("Spatial hash grid too large", :252-254).  One host round trip

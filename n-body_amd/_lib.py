@@ -91,6 +91,7 @@ PROTOTYPES = {
     "nbody_hip_grid_create": (C.c_int, [_P, C.c_size_t, C.c_float, C.POINTER(_P)]),
     "nbody_hip_grid_destroy": (C.c_int, [_P]),
     "nbody_hip_grid_set_cell_size": (C.c_int, [_P, C.c_float]),
+    "nbody_hip_grid_tuning": (C.c_int, [_P, C.c_int]),
     "nbody_hip_grid_build": (C.c_int, [_P, _PD]),
     "nbody_hip_grid_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
     "nbody_hip_grid_info": (C.c_int, [_P, C.POINTER(C.c_int * 3), C.POINTER(C.c_int),

@@ -487,6 +487,10 @@ class SpatialHashGrid:
         check(self.ctx._lib.nbody_hip_grid_set_cell_size(self._h, size))
         self.cell_size_ = float(size)
 
+    def tuning(self, kernel: int = 0):
+        """force kernel: 0 automatic, 1 cell-run, 2 / 3 wave-per-cell with 1 / 2 bodies per lane"""
+        check(self.ctx._lib.nbody_hip_grid_tuning(self._h, kernel))
+
     def build(self, d_particles: ParticleData):
         s = d_particles.struct()
         self._last_count = d_particles.count

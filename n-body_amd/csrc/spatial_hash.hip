@@ -38,6 +38,18 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 namespace nbh {
 
 constexpr int HTS = 256;  // sources per LDS tile
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// |d|^2 as nvcc's default contraction forms the reference's `dx*dx + dy*dy + dz*dz`
+// (force_spatial_hash.cu:131): one product, two fused multiply-adds.  The cutoff decision is taken on
+// THIS value, in the kernels and in the oracle alike, so both sides take bit-identical decisions.
+__device__ __forceinline__ float hash_dist2(float dx, float dy, float dz) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ f2 hash_dist2(f2 dx, f2 dy, f2 dz) {
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
 
 __global__ void bbox_init_kernel(unsigned int* enc) {
   if (threadIdx.x < 3) enc[threadIdx.x] = 0xffffffffu;      // mins
@@ -192,6 +204,19 @@ __global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const float4* __r
   if (k < n) out[k] = posm[idx[k]];
 }
 
+// cell_lb[c] = number of bodies whose cell id is below c (= sorted position of the first body of cell
+// c), for c = 0 .. total: the thread at sorted position k fills the cells between its predecessor's
+// cell and its own.  Only built for grids that are not much larger than the body list (the gaps a
+// thread fills are short then); it replaces the binary searches of the force kernel by direct reads.
+__global__ __launch_bounds__(kBlock) void cell_lb_kernel(const unsigned int* __restrict__ keys, int n,
+                                                         long long total, int* __restrict__ cell_lb) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k > n) return;
+  const long long lo = k == 0 ? 0 : (long long)keys[k - 1] + 1;
+  const long long hi = k == n ? total : (long long)keys[k];
+  for (long long c = lo; c <= hi; c++) cell_lb[c] = k;
+}
+
 // per-cell [start, end) for the inspection API (copyCellDataToHost); empty cells stay 0/0
 __global__ __launch_bounds__(kBlock) void cell_ranges_kernel(const unsigned int* __restrict__ keys,
                                                              int n, int* __restrict__ cell_start,
@@ -308,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const float dx = s[q].x - pi.x, dy = s[q].y - pi.y, dz = s[q].z - pi.z;
-              const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+              const float d2 = hash_dist2(dx, dy, dz);
               bool ok = d2 < cutoff2;                           // :131, unsoftened distance
               if (GUARD) ok = ok && (d2 > 0.f);                 // coincident / self: contributes 0
               if (STRICT) ok = ok && (abs(tile_cx[b][k + q] - cxi) <= 1);
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
           for (; k < ke; k++) {
             const float4 s = tile[b][k];
             const float dx = s.x - pi.x, dy = s.y - pi.y, dz = s.z - pi.z;
-            const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+            const float d2 = hash_dist2(dx, dy, dz);
             const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
             bool ok = d2 < cutoff2;
             if (GUARD) ok = ok && (d2 > 0.f);
@@ -348,6 +373,255 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Force kernel for grids with a cell_lb array: ONE WAVE PER CELL.
+// The wave's targets are the cnt bodies of one cell, and every one of them has the SAME 27-cell
+// window: nine contiguous runs of the cell-ordered list (cells cx-1..cx+1 of the rows y+-1, z+-1),
+// which the wave gathers into its own LDS region as one flat list -- exactly the candidates of the
+// reference's search (force_spatial_hash.cu:104-129), no row overhang, no |cx_j - cx_i| test, no
+// block barrier.  The 64 lanes are T target slots x S slices (T = ceil(cnt / R), S = 64 / T): slice s
+// takes the window entries s, s + S, s + 2S, ... so the lanes of one LDS read touch S consecutive
+// float4 (conflict-free, each broadcast to T lanes), and every lane does useful work on a candidate
+// of ITS cell's window: 27 rho candidate pairs per body instead of the 54 rho of the cell-run kernel.
+// Each lane keeps R targets in registers (one LDS read, R pair evaluations).  Slice partials are
+// fp32 per <= 32 entries, folded into fp64, and summed over the slices through LDS at the end.
+// ---------------------------------------------------------------------------------------
+constexpr int kWinCap = 512;  // window entries a wave holds in LDS at a time (8 KiB)
+// one window entry against the lane's targets: R = 1 scalar, R even -> R/2 packed pairs
+template <bool GUARD, int R>
+struct CellTargets {
+  static constexpr int NP = R / 2;
+  f2 px[NP], py[NP], pz[NP], ax[NP], ay[NP], az[NP];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j < NP; j++) ax[j] = ay[j] = az[j] = (f2)(0.f);
+  }
+  __device__ __forceinline__ void set(int q, float x, float y, float z) {
+    px[q >> 1][q & 1] = x; py[q >> 1][q & 1] = y; pz[q >> 1][q & 1] = z;
+  }
+  __device__ __forceinline__ void pair(const float4 s, float cutoff2, float eps2) {
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      const f2 dx = (f2)(s.x) - px[j], dy = (f2)(s.y) - py[j], dz = (f2)(s.z) - pz[j];
+      const f2 d2 = hash_dist2(dx, dy, dz);
+      const f2 de = d2 + (f2)(eps2);
+      f2 inv;
+      inv.x = __builtin_amdgcn_rsqf(de.x);
+      inv.y = __builtin_amdgcn_rsqf(de.y);
+      f2 f = (inv * (f2)(s.w)) * (inv * inv);
+      bool ok0 = d2.x < cutoff2, ok1 = d2.y < cutoff2;  // :131, unsoftened distance
+      if (GUARD) { ok0 = ok0 && (d2.x > 0.f); ok1 = ok1 && (d2.y > 0.f); }  // coincident / self: contributes 0
+      f.x = ok0 ? f.x : 0.f;
+      f.y = ok1 ? f.y : 0.f;
+      ax[j] = __builtin_elementwise_fma(f, dx, ax[j]);
+      ay[j] = __builtin_elementwise_fma(f, dy, ay[j]);
+      az[j] = __builtin_elementwise_fma(f, dz, az[j]);
+    }
+  }
+  __device__ __forceinline__ float get(int q, int c) const {
+    return c == 0 ? ax[q >> 1][q & 1] : (c == 1 ? ay[q >> 1][q & 1] : az[q >> 1][q & 1]);
+  }
+};
+template <bool GUARD>
+struct CellTargets<GUARD, 1> {
+  float px, py, pz, ax, ay, az;
+  __device__ __forceinline__ void clear() { ax = ay = az = 0.f; }
+  __device__ __forceinline__ void set(int, float x, float y, float z) { px = x; py = y; pz = z; }
+  __device__ __forceinline__ void pair(const float4 s, float cutoff2, float eps2) {
+    const float dx = s.x - px, dy = s.y - py, dz = s.z - pz;
+    const float d2 = hash_dist2(dx, dy, dz);
+    const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+    bool ok = d2 < cutoff2;
+    if (GUARD) ok = ok && (d2 > 0.f);
+    const float f = ok ? (s.w * inv) * (inv * inv) : 0.f;
+    ax = __builtin_fmaf(f, dx, ax);
+    ay = __builtin_fmaf(f, dy, ay);
+    az = __builtin_fmaf(f, dz, az);
+  }
+  __device__ __forceinline__ float get(int, int c) const { return c == 0 ? ax : (c == 1 ? ay : az); }
+};
+
+// KC consecutive cells per wave, software-pipelined: while the wave evaluates cell c out of LDS, the
+// loads of cell c+1's window are already in flight (into registers), so that only the first of a
+// wave's cells pays the global-memory latency of its lookups.
+constexpr int kCellsPerWave = 4;
+
+template <bool GUARD, int R>
+__global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
+    const float4* __restrict__ sorted, const int* __restrict__ cell_lb, const int* __restrict__ idx,
+    int gx, int gy, int gz, long long total, int blocks_per_xcd, float cutoff2, float eps2, float G,
+    float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
+    float4* __restrict__ acc4) {
+  constexpr int KC = kCellsPerWave;
+  __shared__ float4 win_all[4][kWinCap];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float4* win = win_all[w];
+  double* red = reinterpret_cast<double*>(win);  // reused after the pair loop: [R][3][64] doubles
+  static_assert(R * 3 * 64 * sizeof(double) <= kWinCap * sizeof(float4), "reduction area");
+  // workgroup b runs on XCD b mod 8: give every XCD one contiguous eighth of the cells (z slabs), so
+  // that neighbouring cells, whose windows overlap, share an L2
+  const long long blk = (long long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
+  const long long cell0 = (blk * 4 + w) * KC;
+  if (cell0 >= total) return;
+
+  // One round of lookups for all KC cells: lane 16 c + r.  r < 9: run r of cell c's window (cells
+  // cx-1..cx+1 of row y + r%3 - 1, z + r/3 - 1): vseg0 = first sorted position, vlen = length;
+  // r = 9: vseg0 = first target of the cell, r = 10: vseg0 = end of its targets.
+  int vseg0 = 0, vlen = 0;
+  {
+    const int c = lane >> 4, r = lane & 15;
+    const long long cell = cell0 + c;
+    if (c < KC && cell < total) {
+      if (r < 9) {
+        const int cx = (int)(cell % gx), cy = (int)((cell / gx) % gy), cz = (int)(cell / ((long long)gx * gy));
+        const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+        if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+          const long long base = ((long long)zz * gy + yy) * gx;
+          vseg0 = cell_lb[base + max(cx - 1, 0)];
+          vlen = cell_lb[base + min(cx + 2, gx)] - vseg0;
+        }
+      } else if (r < 11) {
+        vseg0 = cell_lb[cell + (r - 9)];
+      }
+    }
+  }
+  // exclusive prefix of the run lengths inside every group of 16 lanes: lane 16 c + r = flat position
+  // of run r, lane 16 c + 9 = window length
+  int vpre;
+  {
+    int incl = vlen;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int up = __shfl_up(incl, off, 16);
+      if ((lane & 15) >= off) incl += up;
+    }
+    vpre = incl - vlen;
+  }
+#define NBH_SEG0(c, r) __builtin_amdgcn_readlane(vseg0, 16 * (c) + (r))
+#define NBH_PRE(c, r) __builtin_amdgcn_readlane(vpre, 16 * (c) + (r))
+
+  float4 pf[9];  // first 64 entries of each run of the NEXT cell to be evaluated
+#define NBH_PREFETCH(c)                                                                              \
+  _Pragma("unroll") for (int r = 0; r < 9; r++) {                                                    \
+    const int p0 = NBH_PRE(c, r), b = min(NBH_PRE(c, r + 1), kWinCap);                               \
+    pf[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+    if (p0 < b) pf[r] = sorted[NBH_SEG0(c, r) + (min(p0 + lane, b - 1) - p0)];                       \
+  }
+  NBH_PREFETCH(0)
+
+#pragma unroll
+  for (int c = 0; c < KC; c++) {
+    const int t0 = NBH_SEG0(c, 9), t1 = NBH_SEG0(c, 10);
+    const int Lw = NBH_PRE(c, 9);
+    bool prefetched = true;  // the registers pf hold batch 0 of this cell
+    for (int tb = t0; tb < t1; tb += 64 * R) {
+      const int cnt = min(t1 - tb, 64 * R);
+      const int T = (cnt + R - 1) / R;  // target slots
+      const int S = 64 / T;             // slices
+      // lane = sl T + slot without a per-lane division: T <= 64 is wave-uniform, so floor(lane / T) is
+      // (lane * ceil(2^16 / T)) >> 16 (exact for lane < 1024)
+      const int magic = (65536 + T - 1) / T;
+      const int sl = (lane * magic) >> 16, slot = lane - sl * T;
+      const bool live = sl < S;
+      CellTargets<GUARD, R> tg;
+      double sx[R], sy[R], sz[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        const float4 p = sorted[min(tb + slot + q * T, t1 - 1)];
+        tg.set(q, p.x, p.y, p.z);
+        sx[q] = sy[q] = sz[q] = 0.0;
+      }
+      for (int vb = 0; vb < Lw; vb += kWinCap) {
+        const int Lb = min(Lw - vb, kWinCap);
+        __builtin_amdgcn_wave_barrier();
+        // the batch [vb, vb + Lb) of the flat window list into LDS: the first 64 entries of every run
+        // come from one round of loads (a run is three cells: usually all of it), the rest in a loop
+        if (prefetched) {
+#pragma unroll
+          for (int r = 0; r < 9; r++) {
+            const int p0 = NBH_PRE(c, r), b = min(NBH_PRE(c, r + 1), Lb);
+            if (p0 + lane < b) win[p0 + lane] = pf[r];
+            for (int v = p0 + 64 + lane; v < b; v += 64) win[v] = sorted[NBH_SEG0(c, r) + (v - p0)];
+          }
+          prefetched = false;
+          if (c + 1 < KC) { NBH_PREFETCH(c + 1) }  // in flight while this cell is evaluated
+        } else {  // later batches of a long window, later chunks of a crowded cell: plain loops
+#pragma unroll
+          for (int r = 0; r < 9; r++) {
+            const int p0 = NBH_PRE(c, r), a = max(p0, vb), b = min(NBH_PRE(c, r + 1), vb + Lb);
+            for (int v = a + lane; v < b; v += 64) win[v - vb] = sorted[NBH_SEG0(c, r) + (v - p0)];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // slice sl takes entries sl, sl + S, ...: all but a lane's last one are inside the batch
+        // (fp32 sums of <= 32 entries, folded into fp64: a dense neighbourhood is hundreds of terms with
+        // heavy cancellation; long fp32 running sums would cost digits)
+        const int iters = (Lb + S - 1) / S;
+        const float4* wp = win + (live ? sl : 0);
+        for (int i0 = 0; i0 < iters - 1; i0 += 32) {
+          const int i1 = min(i0 + 32, iters - 1);
+          tg.clear();
+#pragma unroll 4
+          for (int it = i0; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+#pragma unroll
+          for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
+        }
+        {  // the lane's last entry may lie past the batch
+          const bool valid = (int)(wp - win) < Lb;
+          float4 s = win[valid ? (int)(wp - win) : 0];
+          if (!valid) s.w = 0.f;
+          tg.clear();
+          tg.pair(s, cutoff2, eps2);
+#pragma unroll
+          for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
+        }
+      }
+      // sum over the slices
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        red[(q * 3 + 0) * 64 + lane] = live ? sx[q] : 0.0;
+        red[(q * 3 + 1) * 64 + lane] = live ? sy[q] : 0.0;
+        red[(q * 3 + 2) * 64 + lane] = live ? sz[q] : 0.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < T) {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          const int t = tb + lane + q * T;
+          if (t < tb + cnt) {
+            double fx = 0.0, fy = 0.0, fz = 0.0;
+            for (int s2 = 0; s2 < S; s2++) {
+              fx += red[(q * 3 + 0) * 64 + lane + s2 * T];
+              fy += red[(q * 3 + 1) * 64 + lane + s2 * T];
+              fz += red[(q * 3 + 2) * 64 + lane + s2 * T];
+            }
+            const int i = idx[t];
+            const float ox = (float)((double)G * fx), oy = (float)((double)G * fy), oz = (float)((double)G * fz);
+            if (acc4) {
+              acc4[i] = make_float4(ox, oy, oz, 0.f);
+            } else {
+              acc_x[i] = ox; acc_y[i] = oy; acc_z[i] = oz;
+            }
+          }
+        }
+      }
+    }
+    if (prefetched && c + 1 < KC) {  // an empty cell (or an empty window): pass the pipeline on
+      __builtin_amdgcn_wave_barrier();
+      NBH_PREFETCH(c + 1)
+    }
+  }
+#undef NBH_SEG0
+#undef NBH_PRE
+#undef NBH_PREFETCH
 }
 
 // z cell coordinate of every body on a given grid (slab assignment of the sharded path)
@@ -381,6 +655,10 @@ struct nbody_hip_grid {
   size_t sort_tmp_bytes = 0;
   int *d_cell_start = nullptr, *d_cell_end = nullptr;  // lazily sized (inspection API only)
   long long cell_capacity = 0;
+  int* d_cell_lb = nullptr;            // first sorted position of every cell (+ 1 entry); dense grids only
+  long long lb_capacity = 0;
+  bool lb_valid = false;
+  int tune_kernel = 0;                 // 0 automatic, 1 cell-run kernel, 2 / 3 / 4 wave-per-cell kernel with R = 1 / 2 / 4
   bool ranges_valid = false;
   // host mirror of the last build
   GridInfo info{};
@@ -392,7 +670,7 @@ static void grid_release(nbody_hip_grid* g) {
   (void)hipFree(g->d_enc); (void)hipFree(g->d_info); (void)hipFree(g->d_keys_a);
   (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_a); (void)hipFree(g->d_idx_b);
   (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_cell_start);
-  (void)hipFree(g->d_cell_end);
+  (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb);
   if (g->h_info) (void)hipHostFree(g->h_info);
   delete g;
 }
@@ -452,7 +730,12 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
   g->cell_size = cell_size;
   return NBODY_HIP_OK;
 }
-
+extern "C" int nbody_hip_grid_tuning(nbody_hip_grid* g, int kernel) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (kernel < 0 || kernel > 4) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..4");
+  g->tune_kernel = kernel;
+  return NBODY_HIP_OK;
+}
 
 static int bits_for(long long total) {
   int b = 1;
@@ -512,6 +795,22 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni,
                      g->d_sorted);
   NBH_LAUNCH_CHECK();
+  g->lb_valid = false;
+  if (g->info.total <= 4LL * (long long)n + 4096) {  // dense enough: per-cell start array for the force kernel
+    if (g->info.total + 1 > g->lb_capacity) {
+      NBH_HIP(hipStreamSynchronize(st));
+      (void)hipFree(g->d_cell_lb);
+      g->d_cell_lb = nullptr;
+      g->lb_capacity = 0;
+      const long long cap = (g->info.total + 1) + (g->info.total + 1) / 2;  // grids grow and shrink with the box
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)cap * sizeof(int)));
+      g->lb_capacity = cap;
+    }
+    hipLaunchKernelGGL(cell_lb_kernel, dim3((ni + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g->d_keys_b, ni,
+                       g->info.total, g->d_cell_lb);
+    NBH_LAUNCH_CHECK();
+    g->lb_valid = true;
+  }
   g->built_count = n;
   g->ranges_valid = false;
   return NBODY_HIP_OK;
@@ -568,6 +867,25 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;  // :312-313
   const bool guard = eps2 < 1e-12f;
   const bool strict = cutoff > g->cell_size;
+  // wave-per-cell kernel: needs the cell_lb array; pays from about two bodies per cell
+  int kern = g->tune_kernel;
+  // measured (tools/hash_kernels.py, profiles/r02_hash_kernels.txt): rho 0.9: cell-run 0.16 ms vs 0.28;
+  // rho 3.7: 0.74 vs 0.31 (R = 1) / 0.49 (R = 2); rho 14.6: 1.87 vs 1.20 / 1.02; rho 107: 6.7 vs 8.1 / 6.1
+  if (kern == 0) kern = !g->lb_valid || rho < 2.0 ? 1 : (rho < 8.0 ? 2 : 3);
+  if (kern != 1 && g->lb_valid) {
+    const long long nblk = (g->info.total + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
+    const int per_xcd = (int)((nblk + 7) / 8);
+#define NBH_CELL_LAUNCH(GD, RR)                                                                        \
+  hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,    \
+                     ctx->stream, g->d_sorted, g->d_cell_lb, g->d_idx_b, gx, gy, gz, g->info.total,      \
+                     per_xcd, cutoff2, eps2, G, ax, ay, az, acc4)
+    if (kern == 2)      { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
+    else if (kern == 4) { if (guard) NBH_CELL_LAUNCH(true, 4); else NBH_CELL_LAUNCH(false, 4); }
+    else                { if (guard) NBH_CELL_LAUNCH(true, 2); else NBH_CELL_LAUNCH(false, 2); }
+#undef NBH_CELL_LAUNCH
+    NBH_LAUNCH_CHECK();
+    return NBODY_HIP_OK;
+  }
 #define NBH_HASH_LAUNCH(GD, ST)                                                                   \
   hipLaunchKernelGGL((hash_force_kernel<GD, ST>), grid, dim3(kBlock), 0, ctx->stream, g->d_sorted, \
                      g->d_keys_b, g->d_idx_b, n, g->d_info, W, cutoff2, eps2, G, ax, ay, az, acc4)
