@@ -368,6 +368,14 @@ ORACLE_API void oracle_hash_grid(size_t n, const float* x, const float* y, const
   oracle_grid_dims(bmin, bmax, cell_size, dims);
 }
 
+/* |d|^2 of the cutoff test as the reference's device code forms it: `dx*dx + dy*dy + dz*dz`
+ * (force_spatial_hash.cu:131) under nvcc's default contraction (-fmad=true) is one product and two
+ * fused multiply-adds.  The HIP kernels write the same chain explicitly, so that both sides take the
+ * cutoff decision (r2 < cutoff^2, :131-135) on bit-identical values -- a pair sitting on the cutoff
+ * sphere to the last ulp would otherwise be counted by one side only, and the truncated force is not
+ * small there.  (This file is compiled with -ffp-contract=off: only explicit fmaf() fuses.) */
+static inline float hash_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+
 /* Forces on an EXPLICIT grid (origin bmin, dims): the sharded path bins every rank's bodies on
  * the global grid.  n_t <= n: only the first n_t bodies are targets (own bodies first, then halo). */
 ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float* x, const float* y,
@@ -405,7 +413,7 @@ ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float
             int j = order[k];
             if (j == (int)i) continue; /* :124 */
             float ddx = x[j] - xi, ddy = y[j] - yi, ddz = z[j] - zi;
-            float r2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            float r2 = hash_dist2(ddx, ddy, ddz);
             if (r2 < cutoff2) { /* :131-135: cutoff on the unsoftened distance */
               float dist2 = r2 + eps2;
               float inv = 1.0f / sqrtf(dist2);
@@ -447,7 +455,7 @@ ORACLE_API void oracle_direct_cutoff_forces(size_t n, const float* x, const floa
     for (size_t j = 0; j < n; j++) {
       if (j == i) continue;
       float dx = x[j] - x[i], dy = y[j] - y[i], dz = z[j] - z[i];
-      float r2 = dx * dx + dy * dy + dz * dz;
+      float r2 = hash_dist2(dx, dy, dz);
       if (r2 < cutoff2) {
         float inv = 1.0f / sqrtf(r2 + eps2);
         float f = G * m[j] * (inv * inv * inv);
