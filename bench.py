@@ -158,7 +158,8 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch, workload=N
             sysm = ShardedHashSystem(ic, 1.0, eps, cell, cutoff, backend=HipBackend(ctx))
             sysm.initial_forces()
             step = lambda: sysm.step(dt)  # noqa: E731
-            path = "z-slab shards, all-reduce bbox, all-to-all migration + halo per step"
+            path = ("z-slab shards: all-reduce bbox, one partition pass + all-reduce of counts, ONE host sync, all-to-all "
+                    "of the migrating bodies, halo all-to-all overlapped with the own x own force kernel")
         else:
             ps = nb.ParticleSystem()
             ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod.SPATIAL_HASH, dt=dt,

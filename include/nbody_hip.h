@@ -254,6 +254,51 @@ NBODY_HIP_API int nbody_hip_grid_build_packed(nbody_hip_grid* grid, const nbody_
                                               const float* bounds);
 NBODY_HIP_API int nbody_hip_grid_compute_forces_packed(nbody_hip_grid* grid, float cutoff, float G, float eps,
                                                        nbody_float4* acc_out);
+/* Bodies [first, first + count) of the last build in CELL ORDER (x fastest, then y, then z: a z layer
+ * is one contiguous run), copied to a DEVICE array.  The sharded step takes a rank's lowest and highest
+ * layer from here: they are the halo its neighbours need.  Asynchronous. */
+NBODY_HIP_API int nbody_hip_grid_sorted_bodies(nbody_hip_grid* grid, size_t first, size_t count, nbody_float4* out);
+/* e3 (multi-GPU spatial hash; no reference counterpart): the z layers [z_first, z_first + z_count) of the
+ * global grid are the only ones later nbody_hip_grid_build_packed calls WITH explicit bounds put bodies
+ * in (a rank's slab, or its slab plus the two halo layers): the per-cell start array of the force kernel
+ * then covers just those layers.  z_count <= 0 (default): the whole grid. */
+NBODY_HIP_API int nbody_hip_grid_set_slab(nbody_hip_grid* grid, int z_first, int z_count);
+/* Forces on the bodies of `targets` that lie in the layers [z_first, z_first + z_count) (z_count <= 0:
+ * all) from the bodies of `sources` -- another grid built on the SAME global box and cell size, or the
+ * same grid.  acc_out has one row per body of `targets` in its input order; only the rows of the bodies
+ * in those layers are written (accumulate != 0: added to).  The sharded step evaluates own x own while
+ * the halo layers are in flight, then boundary layers x halo with accumulate.  Both grids must be dense
+ * enough to carry a per-cell start array (NBODY_HIP_ERR_STATE otherwise: use the one-grid path). */
+NBODY_HIP_API int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* targets, nbody_hip_grid* sources, int z_first,
+                                                    int z_count, float cutoff, float G, float eps,
+                                                    nbody_float4* acc_out, int accumulate);
+/* One partition pass of a rank's bodies after the drift (csrc/slab.hip).  gbox_dev: DEVICE array
+ * {min x,y,z, max x,y,z} of ALL ranks' bodies (the all-reduced nbody_hip_bbox_packed result, unpadded);
+ * the global grid is derived from it on the device exactly as SpatialHashGrid::build does (ref:
+ * force_spatial_hash.cu:225-246).  Layer z belongs to rank ((z + 1) world - 1) / gz.  Outputs, all DEVICE:
+ *   rows_out        the bodies that CHANGE OWNER, 16 floats each {x,y,z,m | vx,vy,vz,0 | ax,ay,az,0 |
+ *                   id,z,0,0 (int bits)}, grouped by new owner (ascending, own rank absent), each group in
+ *                   input order; capacity n rows
+ *   holes_out       the input positions of those bodies, ascending; capacity n ints
+ *   send_matrix_dev world x world ints, zeroed, row `rank` = bodies per new owner, entry [rank][rank] = the
+ *                   bodies that stay (sum over ranks = who sends how many rows to whom)
+ *   hist_dev        hist_cap ints: this rank's bodies per layer (sum over ranks = population of every
+ *                   layer, hence every rank's new body count and the size of its halo layers)
+ *   info_dev        4 ints: gx, gy, gz, and 1 if gz > hist_cap (the caller must fall back)
+ * The bodies that stay are not touched.  Asynchronous; gid may be NULL (ids = input positions); with
+ * world == 1 rows_out / holes_out may be NULL. */
+NBODY_HIP_API int nbody_hip_slab_partition(nbody_hip_ctx* ctx, const nbody_float4* posm, const nbody_float4* vel,
+                                           const nbody_float4* acc, const int* gid, size_t n, const float* gbox_dev,
+                                           float cell_size, int world, int rank, int hist_cap, float* rows_out,
+                                           int* holes_out, int* send_matrix_dev, int* hist_dev, int* info_dev);
+/* After the exchange: n_old bodies (arrays with room for n_old - n_holes + n_arrivals) of which the slots
+ * holes[0..n_holes) (ascending, as written by the partition) are vacant, and n_arrivals rows received from
+ * the other ranks -> the n_old - n_holes + n_arrivals bodies of the rank, contiguous from slot 0: arrivals go
+ * into the vacant slots in order, surplus arrivals behind the old end, surplus slots are closed with the bodies
+ * taken from the end.  Deterministic; moves 64 bytes per migrating body and nothing else.  gid may be NULL. */
+NBODY_HIP_API int nbody_hip_slab_fill(nbody_hip_ctx* ctx, const float* rows, size_t n_arrivals, const int* holes,
+                                      size_t n_holes, size_t n_old, nbody_float4* posm, nbody_float4* vel,
+                                      nbody_float4* acc, int* gid);
 /* min/max of packed bodies into a DEVICE array of 6 floats {lo x,y,z, hi x,y,z} (async; the ranks
  * all-reduce it).  ref: computeBoundingBoxKernel, force_barnes_hut.cu:66-110 */
 NBODY_HIP_API int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t count,

@@ -100,6 +100,13 @@ PROTOTYPES = {
     "nbody_hip_grid_copy_cell_data": (C.c_int, [_P, _P, _P, _P, _P]),
     "nbody_hip_grid_build_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "nbody_hip_grid_compute_forces_packed": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P]),
+    "nbody_hip_grid_sorted_bodies": (C.c_int, [_P, C.c_size_t, C.c_size_t, _P]),
+    "nbody_hip_grid_set_slab": (C.c_int, [_P, C.c_int, C.c_int]),
+    "nbody_hip_grid_forces_pair_packed": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P,
+                                                    C.c_int]),
+    "nbody_hip_slab_partition": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_int, C.c_int, C.c_int,
+                                           _P, _P, _P, _P, _P]),
+    "nbody_hip_slab_fill": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P]),
     "nbody_hip_bbox_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "nbody_hip_cell_z_packed": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_int, _P]),
     "nbody_hip_tree_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

@@ -209,12 +209,16 @@ __global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const float4* __r
 // cell and its own.  Only built for grids that are not much larger than the body list (the gaps a
 // thread fills are short then); it replaces the binary searches of the force kernel by direct reads.
 __global__ __launch_bounds__(kBlock) void cell_lb_kernel(const unsigned int* __restrict__ keys, int n,
-                                                         long long total, int* __restrict__ cell_lb) {
+                                                         long long base, long long count,
+                                                         int* __restrict__ cell_lb) {
+  // covers the cells [base, base + count] (the whole grid, or the z-slab of a rank)
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k > n) return;
-  const long long lo = k == 0 ? 0 : (long long)keys[k - 1] + 1;
-  const long long hi = k == n ? total : (long long)keys[k];
-  for (long long c = lo; c <= hi; c++) cell_lb[c] = k;
+  long long lo = k == 0 ? base : (long long)keys[k - 1] + 1;
+  long long hi = k == n ? base + count : (long long)keys[k];
+  if (lo < base) lo = base;
+  if (hi > base + count) hi = base + count;
+  for (long long c = lo; c <= hi; c++) cell_lb[c - base] = k;
 }
 
 // per-cell [start, end) for the inspection API (copyCellDataToHost); empty cells stay 0/0
@@ -448,12 +452,26 @@ struct CellTargets<GUARD, 1> {
 // wave's cells pays the global-memory latency of its lookups.
 constexpr int kCellsPerWave = 4;
 
+// A grid as the force kernel sees it.  lb covers the cells [base, base + count] of the (global) grid --
+// the whole grid, or the z-slab a rank holds (sharded path); cells outside hold no bodies of this grid.
+struct CellGridView {
+  const float4* sorted;
+  const int* lb;
+  const int* idx;
+  long long base, count;
+  __device__ __forceinline__ int lower(long long c) const {
+    const long long k = c - base;
+    return lb[k < 0 ? 0 : (k > count ? count : k)];
+  }
+};
+
+// Targets: the bodies of grid `tg` in the cells [cell_first, cell_end); sources: grid `sg` (the same grid,
+// or -- sharded path -- the halo layers received from the neighbouring ranks).  ACCUM adds to acc4.
 template <bool GUARD, int R>
 __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
-    const float4* __restrict__ sorted, const int* __restrict__ cell_lb, const int* __restrict__ idx,
-    int gx, int gy, int gz, long long total, int blocks_per_xcd, float cutoff2, float eps2, float G,
-    float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
-    float4* __restrict__ acc4) {
+    const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
+    long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
+    float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate) {
   constexpr int KC = kCellsPerWave;
   __shared__ float4 win_all[4][kWinCap];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -461,11 +479,14 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
   float4* win = win_all[w];
   double* red = reinterpret_cast<double*>(win);  // reused after the pair loop: [R][3][64] doubles
   static_assert(R * 3 * 64 * sizeof(double) <= kWinCap * sizeof(float4), "reduction area");
+  const float4* __restrict__ sorted = sgv.sorted;    // window entries
+  const float4* __restrict__ tsorted = tgv.sorted;   // targets
+  const int* __restrict__ idx = tgv.idx;
   // workgroup b runs on XCD b mod 8: give every XCD one contiguous eighth of the cells (z slabs), so
   // that neighbouring cells, whose windows overlap, share an L2
   const long long blk = (long long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
-  const long long cell0 = (blk * 4 + w) * KC;
-  if (cell0 >= total) return;
+  const long long cell0 = cell_first + (blk * 4 + w) * KC;
+  if (cell0 >= cell_end) return;
 
   // One round of lookups for all KC cells: lane 16 c + r.  r < 9: run r of cell c's window (cells
   // cx-1..cx+1 of row y + r%3 - 1, z + r/3 - 1): vseg0 = first sorted position, vlen = length;
@@ -474,17 +495,17 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
   {
     const int c = lane >> 4, r = lane & 15;
     const long long cell = cell0 + c;
-    if (c < KC && cell < total) {
+    if (c < KC && cell < cell_end) {
       if (r < 9) {
         const int cx = (int)(cell % gx), cy = (int)((cell / gx) % gy), cz = (int)(cell / ((long long)gx * gy));
         const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
         if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
           const long long base = ((long long)zz * gy + yy) * gx;
-          vseg0 = cell_lb[base + max(cx - 1, 0)];
-          vlen = cell_lb[base + min(cx + 2, gx)] - vseg0;
+          vseg0 = sgv.lower(base + max(cx - 1, 0));
+          vlen = sgv.lower(base + min(cx + 2, gx)) - vseg0;
         }
       } else if (r < 11) {
-        vseg0 = cell_lb[cell + (r - 9)];
+        vseg0 = tgv.lower(cell + (r - 9));
       }
     }
   }
@@ -530,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       double sx[R], sy[R], sz[R];
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        const float4 p = sorted[min(tb + slot + q * T, t1 - 1)];
+        const float4 p = tsorted[min(tb + slot + q * T, t1 - 1)];
         tg.set(q, p.x, p.y, p.z);
         sx[q] = sy[q] = sz[q] = 0.0;
       }
@@ -606,7 +627,12 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
             const int i = idx[t];
             const float ox = (float)((double)G * fx), oy = (float)((double)G * fy), oz = (float)((double)G * fz);
             if (acc4) {
-              acc4[i] = make_float4(ox, oy, oz, 0.f);
+              if (accumulate) {
+                const float4 o = acc4[i];
+                acc4[i] = make_float4(o.x + ox, o.y + oy, o.z + oz, 0.f);
+              } else {
+                acc4[i] = make_float4(ox, oy, oz, 0.f);
+              }
             } else {
               acc_x[i] = ox; acc_y[i] = oy; acc_z[i] = oz;
             }
@@ -658,6 +684,8 @@ struct nbody_hip_grid {
   int* d_cell_lb = nullptr;            // first sorted position of every cell (+ 1 entry); dense grids only
   long long lb_capacity = 0;
   bool lb_valid = false;
+  long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
+  int slab_z0 = 0, slab_nz = 0;         // packed builds: z layers this grid holds (nz <= 0: all)
   int tune_kernel = 0;                 // 0 automatic, 1 cell-run kernel, 2 / 3 / 4 wave-per-cell kernel with R = 1 / 2 / 4
   bool ranges_valid = false;
   // host mirror of the last build
@@ -748,7 +776,7 @@ static int bits_for(long long total) {
 // the GLOBAL box so that every rank bins on the same grid.
 // soa != nullptr: posm is a scratch array to be filled from the SoA bodies (fused with the bounding box)
 static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const float* bounds,
-                             const nbody_particle_data* soa = nullptr) {
+                             const nbody_particle_data* soa = nullptr, bool slab = false) {
   nbody_hip_ctx* ctx = g->ctx;
   // the grid dimensions come back to the host every build (they size the force launch)
   NBH_NOT_CAPTURABLE(ctx, "the spatial-hash grid build");
@@ -796,20 +824,34 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
                      g->d_sorted);
   NBH_LAUNCH_CHECK();
   g->lb_valid = false;
-  if (g->info.total <= 4LL * (long long)n + 4096) {  // dense enough: per-cell start array for the force kernel
-    if (g->info.total + 1 > g->lb_capacity) {
-      NBH_HIP(hipStreamSynchronize(st));
-      (void)hipFree(g->d_cell_lb);
-      g->d_cell_lb = nullptr;
-      g->lb_capacity = 0;
-      const long long cap = (g->info.total + 1) + (g->info.total + 1) / 2;  // grids grow and shrink with the box
-      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)cap * sizeof(int)));
-      g->lb_capacity = cap;
+  {
+    // cells the per-cell start array covers: the whole grid, or the z layers of this rank's slab
+    long long base = 0, count = g->info.total;
+    if (slab && g->slab_nz > 0) {
+      const long long layer = (long long)g->info.dims[0] * g->info.dims[1];
+      const long long z0 = g->slab_z0 < 0 ? 0 : g->slab_z0;
+      long long z1 = (long long)g->slab_z0 + g->slab_nz;
+      if (z1 > g->info.dims[2]) z1 = g->info.dims[2];
+      base = z0 * layer;
+      count = z1 > z0 ? (z1 - z0) * layer : 0;
     }
-    hipLaunchKernelGGL(cell_lb_kernel, dim3((ni + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g->d_keys_b, ni,
-                       g->info.total, g->d_cell_lb);
-    NBH_LAUNCH_CHECK();
-    g->lb_valid = true;
+    if (count > 0 && count <= 4LL * (long long)n + 4096) {  // dense enough: gaps a thread fills are short
+      if (count + 1 > g->lb_capacity) {
+        NBH_HIP(hipStreamSynchronize(st));
+        (void)hipFree(g->d_cell_lb);
+        g->d_cell_lb = nullptr;
+        g->lb_capacity = 0;
+        const long long cap = (count + 1) + (count + 1) / 2;  // grids grow and shrink with the box
+        NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)cap * sizeof(int)));
+        g->lb_capacity = cap;
+      }
+      hipLaunchKernelGGL(cell_lb_kernel, dim3((ni + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g->d_keys_b, ni,
+                         base, count, g->d_cell_lb);
+      NBH_LAUNCH_CHECK();
+      g->lb_valid = true;
+      g->lb_base = base;
+      g->lb_count = count;
+    }
   }
   g->built_count = n;
   g->ranges_valid = false;
@@ -845,7 +887,26 @@ extern "C" int nbody_hip_grid_build_packed(nbody_hip_grid* g, const nbody_float4
       if (!(bounds[3 + a] >= bounds[a]) || !(bounds[3 + a] - bounds[a] < INFINITY))
         return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "invalid grid bounds");
   NBH_HIP(hipSetDevice(g->ctx->device));
-  return grid_build_packed(g, const_cast<float4*>(reinterpret_cast<const float4*>(posm)), n, bounds);
+  return grid_build_packed(g, const_cast<float4*>(reinterpret_cast<const float4*>(posm)), n, bounds, nullptr,
+                           bounds != nullptr);
+}
+
+static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const CellGridView& sv, int gx, int gy,
+                              int gz, long long cell_first, long long cell_end, int kern, bool guard, float cutoff2,
+                              float eps2, float G, float* ax, float* ay, float* az, float4* acc4, int accumulate) {
+  if (cell_end <= cell_first) return NBODY_HIP_OK;
+  const long long nblk = (cell_end - cell_first + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
+  const int per_xcd = (int)((nblk + 7) / 8);
+#define NBH_CELL_LAUNCH(GD, RR)                                                                        \
+  hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,    \
+                     ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, \
+                     az, acc4, accumulate)
+  if (kern == 2)      { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
+  else if (kern == 4) { if (guard) NBH_CELL_LAUNCH(true, 4); else NBH_CELL_LAUNCH(false, 4); }
+  else                { if (guard) NBH_CELL_LAUNCH(true, 2); else NBH_CELL_LAUNCH(false, 2); }
+#undef NBH_CELL_LAUNCH
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
 }
 
 static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float eps, float* ax,
@@ -857,7 +918,7 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   const int n = (int)g->built_count;
   const int gx = g->info.dims[0], gy = g->info.dims[1], gz = g->info.dims[2];
   // cells per wave: ~64 targets per wave at the mean occupancy
-  const double rho = (double)n / (double)g->info.total;
+  const double rho = (double)n / (double)(g->lb_valid && g->lb_count > 0 ? g->lb_count : g->info.total);
   int W = rho > 0 ? (int)(64.0 / rho + 0.5) : kMaxWv;
   if (W < 1) W = 1;
   if (W > kMaxWv) W = kMaxWv;
@@ -873,18 +934,9 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   // rho 3.7: 0.74 vs 0.31 (R = 1) / 0.49 (R = 2); rho 14.6: 1.87 vs 1.20 / 1.02; rho 107: 6.7 vs 8.1 / 6.1
   if (kern == 0) kern = !g->lb_valid || rho < 2.0 ? 1 : (rho < 8.0 ? 2 : 3);
   if (kern != 1 && g->lb_valid) {
-    const long long nblk = (g->info.total + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
-    const int per_xcd = (int)((nblk + 7) / 8);
-#define NBH_CELL_LAUNCH(GD, RR)                                                                        \
-  hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,    \
-                     ctx->stream, g->d_sorted, g->d_cell_lb, g->d_idx_b, gx, gy, gz, g->info.total,      \
-                     per_xcd, cutoff2, eps2, G, ax, ay, az, acc4)
-    if (kern == 2)      { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
-    else if (kern == 4) { if (guard) NBH_CELL_LAUNCH(true, 4); else NBH_CELL_LAUNCH(false, 4); }
-    else                { if (guard) NBH_CELL_LAUNCH(true, 2); else NBH_CELL_LAUNCH(false, 2); }
-#undef NBH_CELL_LAUNCH
-    NBH_LAUNCH_CHECK();
-    return NBODY_HIP_OK;
+    const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
+    return launch_cell_forces(ctx, view, view, gx, gy, gz, g->lb_base, g->lb_base + g->lb_count, kern, guard, cutoff2,
+                              eps2, G, ax, ay, az, acc4, 0);
   }
 #define NBH_HASH_LAUNCH(GD, ST)                                                                   \
   hipLaunchKernelGGL((hash_force_kernel<GD, ST>), grid, dim3(kBlock), 0, ctx->stream, g->d_sorted, \
@@ -912,6 +964,59 @@ extern "C" int nbody_hip_grid_compute_forces_packed(nbody_hip_grid* g, float cut
   if (!acc_out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid has not been built");
   return grid_forces_common(g, cutoff, G, eps, nullptr, nullptr, nullptr, reinterpret_cast<float4*>(acc_out));
+}
+
+extern "C" int nbody_hip_grid_sorted_bodies(nbody_hip_grid* g, size_t first, size_t count, nbody_float4* out) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (count == 0) return NBODY_HIP_OK;
+  if (!out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (g->built_count == 0 || first + count > g->built_count)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "range [%zu, %zu) outside the %zu bodies of the last build", first,
+                    first + count, g->built_count);
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  NBH_HIP(hipMemcpyAsync(out, g->d_sorted + first, count * sizeof(float4), hipMemcpyDeviceToDevice, g->ctx->stream));
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_set_slab(nbody_hip_grid* g, int z_first, int z_count) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  g->slab_z0 = z_first;
+  g->slab_nz = z_count;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* gt, nbody_hip_grid* gs, int z_first, int z_count,
+                                                 float cutoff, float G, float eps, nbody_float4* acc_out,
+                                                 int accumulate) {
+  if (!gt || !gs) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!acc_out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (gt->built_count == 0 || gs->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid has not been built");
+  if (!(cutoff > 0.0f) || !(cutoff < INFINITY))
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Spatial hash cutoff must be positive and finite");
+  if (!gt->lb_valid || !gs->lb_valid)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid too sparse for the two-grid force kernel (no per-cell start array)");
+  for (int a = 0; a < 3; a++)
+    if (gt->info.dims[a] != gs->info.dims[a] || gt->info.bmin[a] != gs->info.bmin[a])
+      return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "the two grids must share origin and dimensions");
+  if (gt->cell_size != gs->cell_size) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "the two grids must share the cell size");
+  nbody_hip_ctx* ctx = gt->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  const int gx = gt->info.dims[0], gy = gt->info.dims[1], gz = gt->info.dims[2];
+  const long long layer = (long long)gx * gy;
+  long long z0 = z_first < 0 ? 0 : z_first, z1 = z_count <= 0 ? gz : (long long)z_first + z_count;
+  if (z1 > gz) z1 = gz;
+  // only cells the target grid's start array covers can hold targets
+  long long c0 = z0 * layer, c1 = z1 * layer;
+  if (c0 < gt->lb_base) c0 = gt->lb_base;
+  if (c1 > gt->lb_base + gt->lb_count) c1 = gt->lb_base + gt->lb_count;
+  const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
+  const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
+  int kern = gt->tune_kernel;
+  if (kern < 2) kern = rho < 8.0 ? 2 : 3;
+  const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
+  const CellGridView sv{gs->d_sorted, gs->d_cell_lb, gs->d_idx_b, gs->lb_base, gs->lb_count};
+  return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f, cutoff2, eps2, G, nullptr, nullptr,
+                            nullptr, reinterpret_cast<float4*>(acc_out), accumulate ? 1 : 0);
 }
 
 extern "C" int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t n,

@@ -42,16 +42,19 @@ class HipBackend:
     def __init__(self, ctx: Context):
         self.ctx = ctx
         self.device = ctx.torch_device
-        self._grid = self._tree = None
+        self._grids = {}
+        self._tree = None
 
     def close(self):
         """Frees the lazily created grid / tree handles (also run at garbage collection)."""
         lib = self.ctx._lib
-        if self._grid is not None and self.ctx.handle.value:
-            lib.nbody_hip_grid_destroy(self._grid)
-        if self._tree is not None and self.ctx.handle.value:
-            lib.nbody_hip_tree_destroy(self._tree)
-        self._grid = self._tree = None
+        if self.ctx.handle.value:
+            for h, _, _ in self._grids.values():
+                lib.nbody_hip_grid_destroy(h)
+            if self._tree is not None:
+                lib.nbody_hip_tree_destroy(self._tree)
+        self._grids = {}
+        self._tree = None
 
     def __del__(self):
         try:
@@ -111,21 +114,78 @@ class HipBackend:
         return cz
 
     def hash_forces(self, posm_all, bounds, cell, cutoff, G, eps):
-        """Accelerations [n,4] of every body of posm_all on the grid with the given padded bounds."""
+        """Accelerations [n,4] of every body of posm_all on the grid with the given padded bounds
+        (one grid, one launch: the fallback of the sharded step for grids too sparse or too tall)."""
         n = posm_all.shape[0]
-        if getattr(self, "_grid_cap", 0) < n or getattr(self, "_grid_cell", None) != cell:
-            if getattr(self, "_grid", None) is not None:
-                self.ctx._lib.nbody_hip_grid_destroy(self._grid)
+        h = self._grid_handle("one", n, cell)
+        check(self.ctx._lib.nbody_hip_grid_set_slab(h, 0, 0))
+        b = (C.c_float * 6)(*bounds)
+        check(self.ctx._lib.nbody_hip_grid_build_packed(h, posm_all.data_ptr(), n, b))
+        acc = torch.empty((n, 4), dtype=torch.float32, device=posm_all.device)
+        check(self.ctx._lib.nbody_hip_grid_compute_forces_packed(h, cutoff, G, eps, acc.data_ptr()))
+        return acc
+
+    def _grid_handle(self, slot, n, cell):
+        """Grid handles by role ("own" bodies of the slab, "halo" layers, "one" = fallback), grown as needed."""
+        grids = self.__dict__.setdefault("_grids", {})
+        cur = grids.get(slot)
+        if cur is None or cur[1] < n or cur[2] != cell:
+            if cur is not None:
+                self.ctx._lib.nbody_hip_grid_destroy(cur[0])
             h = C.c_void_p()
             cap = int(n * 1.5) + 1024
             check(self.ctx._lib.nbody_hip_grid_create(self.ctx.handle, cap, cell, C.byref(h)))
-            self._grid, self._grid_cap, self._grid_cell = h, cap, cell
-        b = (C.c_float * 6)(*bounds)
-        check(self.ctx._lib.nbody_hip_grid_build_packed(self._grid, posm_all.data_ptr(), n, b))
-        acc = torch.empty((n, 4), dtype=torch.float32, device=posm_all.device)
-        check(self.ctx._lib.nbody_hip_grid_compute_forces_packed(self._grid, cutoff, G, eps,
-                                                                 acc.data_ptr()))
-        return acc
+            grids[slot] = cur = (h, cap, cell)
+        return cur[0]
+
+    def slab_partition(self, posm, vel, acc, gid, gbox, cell, world, rank, hist_cap):
+        """One pass over the rank's bodies (csrc/slab.hip): the bodies that change owner as rows [.,16]
+        grouped by new owner + the slots they vacate, this rank's row of the send matrix [W,W] followed by
+        its layer histogram [hist_cap], and {gx, gy, gz, overflow}; all on the device, nothing comes back
+        to the host here.  The bodies that stay are not touched."""
+        n = posm.shape[0]
+        dev = gbox.device
+        rows = torch.empty((n if world > 1 else 0, 16), dtype=torch.float32, device=dev)
+        holes = torch.empty(n if world > 1 else 0, dtype=torch.int32, device=dev)
+        stats = torch.empty(world * world + hist_cap, dtype=torch.int32, device=dev)
+        info = torch.empty(4, dtype=torch.int32, device=dev)
+        check(self.ctx._lib.nbody_hip_slab_partition(
+            self.ctx.handle, posm.data_ptr(), vel.data_ptr(), acc.data_ptr(), gid.data_ptr(), n, gbox.data_ptr(),
+            cell, world, rank, hist_cap, rows.data_ptr(), holes.data_ptr(), stats.data_ptr(),
+            stats.data_ptr() + 4 * world * world, info.data_ptr()))
+        return rows, holes, stats, info
+
+    def slab_fill(self, posm, vel, acc, gid, n_old, holes, n_holes, arrivals):
+        """The capacity arrays after the exchange: arrivals into the vacated slots, surplus appended, surplus
+        slots closed from the end (nbody_hip_slab_fill).  The arrays must hold n_old - n_holes + arrivals rows."""
+        check(self.ctx._lib.nbody_hip_slab_fill(self.ctx.handle, arrivals.data_ptr(), arrivals.shape[0],
+                                                holes.data_ptr(), n_holes, n_old, posm.data_ptr(), vel.data_ptr(),
+                                                acc.data_ptr(), gid.data_ptr()))
+
+    def grid_build(self, slot, posm, bounds, cell, z_first, z_count):
+        """Grid `slot` over `posm` on the global box `bounds`; the bodies lie in layers [z_first, +z_count)."""
+        h = self._grid_handle(slot, posm.shape[0], cell)
+        check(self.ctx._lib.nbody_hip_grid_set_slab(h, z_first, z_count))
+        check(self.ctx._lib.nbody_hip_grid_build_packed(h, posm.data_ptr(), posm.shape[0], (C.c_float * 6)(*bounds)))
+
+    def grid_sorted(self, slot, first, count, out):
+        """out[:count] = bodies [first, first+count) of grid `slot` in cell order (a z layer is one run)."""
+        check(self.ctx._lib.nbody_hip_grid_sorted_bodies(self._grids[slot][0], first, count, out.data_ptr()))
+
+    def grid_forces(self, slot_t, slot_s, z_first, z_count, cutoff, G, eps, acc_out, accumulate):
+        """acc_out rows of grid slot_t's bodies in layers [z_first, +z_count) (+)= forces from grid slot_s.
+        False when a grid is too sparse for the two-grid kernel (the caller falls back)."""
+        rc = self.ctx._lib.nbody_hip_grid_forces_pair_packed(self._grids[slot_t][0], self._grids[slot_s][0], z_first,
+                                                             z_count, cutoff, G, eps, acc_out.data_ptr(),
+                                                             1 if accumulate else 0)
+        if rc == -4:  # NBODY_HIP_ERR_STATE: no per-cell start array
+            return False
+        check(rc)
+        return True
+
+    def to_host(self, *tensors):
+        """The step's one host synchronisation: small device tensors -> numpy."""
+        return [t.cpu().numpy() for t in tensors]
 
 
 def shard_bounds(n: int, world: int, rank: int):
@@ -333,18 +393,30 @@ def layer_owner(gz: int, world: int) -> np.ndarray:
 class ShardedHashSystem:
     """Spatial hash sharded by z-slabs of cells: the linear cell id
     x + y gx + z gx gy (force_spatial_hash.cu:48) makes a range of z layers a contiguous block of
-    the cell-ordered body list, so rank r owns the bodies of its layers.  Per force evaluation:
+    the cell-ordered body list, so rank r owns the bodies of the layers [r gz / W, (r+1) gz / W).
+    One force evaluation (after the drift), with ONE host synchronisation and four collectives:
 
-        global box    local min/max (HIP) -> all-reduce MIN/MAX of 6 floats -> every rank bins on
-                      the SAME grid (box padded by 0.001, dims = ceil(extent/cell)+1, like the
-                      reference's build, force_spatial_hash.cu:225-246)
-        migration     bodies whose layer now belongs to another rank move there (all-to-all of
-                      {x,y,z,m}, velocity, previous acceleration: 48 B/body, few bodies per step)
-        halo          the bodies of a rank's lowest / highest layer are sent to the owner of the
-                      layer below / above (16 B/body: one cell layer per direction)
-        forces        27-cell kernel on [own bodies; halo bodies]; only the own part is kept
+        global box    local min/max (HIP) -> one all-reduce (max of {-lo, hi}) -> every rank bins on the
+                      SAME grid (box padded by 0.001, dims = ceil(extent/cell)+1, like the reference's
+                      build, force_spatial_hash.cu:225-246); the grid is derived on the device
+        partition     ONE pass over the rank's bodies (csrc/slab.hip): new layer and owner of every
+                      body, 64-byte rows grouped by owner, the rank's row of the W x W send matrix and its
+                      bodies-per-layer histogram -> one all-reduce (sum): every rank now knows who sends
+                      it how many rows, how many bodies it will own and how many its halo layers hold
+        host sync     box, matrix, histogram (the grid size decides validity, as in the reference)
+        migration     one all-to-all of rows {x,y,z,m, v, a_old, id} (exact sizes; 64 B/body, few bodies)
+        own grid      cell-ordered build of the rank's bodies: its lowest and highest layer are the head
+                      and the tail of that order -- the halo its neighbours need, no selection pass
+        halo          one all-to-all of those two layers (16 B/body), ASYNCHRONOUS ...
+        own x own     ... while the 27-cell kernel evaluates every own body against the own bodies
+        halo grid     after the halo has arrived: a grid over the two received layers, and the kernel again
+                      for the rank's two boundary layers against it, accumulated
 
-    One Velocity-Verlet step = drift, the above, kick (ref: Integrator::integrate)."""
+    One Velocity-Verlet step = drift, the above, kick (ref: Integrator::integrate).  Grids that are too
+    sparse for the per-cell start arrays of the two-grid kernel, or taller than HIST_CAP layers, take the
+    older one-grid path (`_compute_forces_generic`: exchange, then one build and one launch)."""
+
+    HIST_CAP = 4096
 
     def __init__(self, ic: dict, G: float, eps: float, cell_size: float, cutoff: float,
                  backend=None, group=None, device=None):
@@ -370,12 +442,41 @@ class ShardedHashSystem:
             if f in ic:
                 vel[:, k] = ic[f][mine]
         dev = self.device
-        self.posm = torch.from_numpy(np.ascontiguousarray(posm.astype(np.float32))).to(dev)
-        self.vel = torch.from_numpy(vel).to(dev)
-        self.acc = torch.zeros((mine.size, 4), dtype=torch.float32, device=dev)
-        self.gid = torch.from_numpy(mine.astype(np.int64)).to(dev)  # global ids (verification only)
+        # the rank's bodies live at the front of capacity arrays (bodies arrive and leave every step);
+        # self.posm / vel / acc / gid are views of the first n rows
+        self._buf = {"posm": torch.from_numpy(np.ascontiguousarray(posm.astype(np.float32))).to(dev),
+                     "vel": torch.from_numpy(vel).to(dev),
+                     "acc": torch.zeros((mine.size, 4), dtype=torch.float32, device=dev),
+                     "acc2": torch.zeros((mine.size, 4), dtype=torch.float32, device=dev),  # swapped with acc
+                     "gid": torch.from_numpy(mine.astype(np.int32)).to(dev)}  # global ids (verification only)
+        self._set_count(mine.size)
         self.halo_bodies = 0
         self.migrated = 0
+        self.path = ""  # "two-grid" (overlapped) or "one-grid" (fallback), of the last evaluation
+
+    # -- storage ------------------------------------------------------------------------------
+    def _set_count(self, n):
+        self.posm, self.vel, self.acc, self.gid = (self._buf[k][:n] for k in ("posm", "vel", "acc", "gid"))
+
+    def _reserve(self, n):
+        """Capacity for n bodies (+ 1/8 slack), keeping the current rows."""
+        if self._buf["posm"].shape[0] >= n:
+            return
+        cap = n + n // 8 + 1024
+        for k, t in self._buf.items():
+            grown = torch.empty((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            grown[:t.shape[0]] = t
+            self._buf[k] = grown
+        self._set_count(self.posm.shape[0])
+
+    def _replace(self, posm, vel, acc, gid):
+        self._buf = {"posm": posm, "vel": vel, "acc": acc, "acc2": torch.empty_like(acc), "gid": gid}
+        self._set_count(posm.shape[0])
+
+    def _adopt_new_accelerations(self):
+        """a <- a_new by swapping the two acceleration arrays (no copy)."""
+        self._buf["acc"], self._buf["acc2"] = self._buf["acc2"], self._buf["acc"]
+        self._set_count(self.posm.shape[0])
 
     # -- grid --------------------------------------------------------------------------------
     def _grid_from_bounds(self, raw6):
@@ -385,15 +486,103 @@ class ShardedHashSystem:
         dims = [int(np.ceil((hi[a] - lo[a]) / f(self.cell))) + 1 for a in range(3)]  # :244-246
         return [float(v) for v in lo], [float(v) for v in hi], dims
 
-    def _global_grid(self):
-        b = self.backend.bbox(self.posm) if self.posm.shape[0] > 0 else torch.tensor(
-            [3e38] * 3 + [-3e38] * 3, dtype=torch.float32, device=self.device)
+    def _global_box(self):
+        """{min x,y,z, max x,y,z} of all ranks' bodies as a device tensor: ONE all-reduce (max of {-lo, hi})."""
+        if self.posm.shape[0] > 0:
+            b = self.backend.bbox(self.posm)
+        else:
+            b = torch.tensor([3e38] * 3 + [-3e38] * 3, dtype=torch.float32, device=self.device)
         if self.world > 1:
-            lo, hi = b[:3].clone(), b[3:].clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-            b = torch.cat([lo, hi])
-        return self._grid_from_bounds(b.cpu().numpy().tolist())
+            m = torch.cat([-b[:3], b[3:]])
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+            b = torch.cat([-m[:3], m[3:]])
+        return b
+
+    def compute_forces(self):
+        b, W, r = self.backend, self.world, self.rank
+        if not hasattr(b, "slab_partition"):
+            return self._compute_forces_generic()
+        dev = self.device
+        n_loc = self.posm.shape[0]
+        box = self._global_box()
+        rows, holes, stats, info = b.slab_partition(self.posm, self.vel, self.acc, self.gid, box, self.cell, W, r,
+                                                    self.HIST_CAP)
+        if W > 1:  # send matrix (every rank filled its row) + bodies per layer, summed over the ranks
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        box_h, stats_h, info_h = b.to_host(box, stats, info)  # the step's one host synchronisation
+        gx, gy, gz, too_tall = (int(v) for v in info_h)
+        if gx * gy * gz > 100000000:  # force_spatial_hash.cu:252-254, on every rank alike
+            from ._lib import ResourceException
+            raise ResourceException("Spatial hash grid too large: reduce cell_size or bounding box")
+        lo, hi, dims = self._grid_from_bounds([float(v) for v in box_h])
+        if too_tall or dims != [gx, gy, gz]:
+            return self._compute_forces_generic((lo, hi, dims))
+        M = stats_h[:W * W].reshape(W, W)
+        hist = stats_h[W * W:W * W + gz]
+        z_lo, z_hi = (r * gz) // W, ((r + 1) * gz) // W
+        send, recv = [int(v) for v in M[r]], [int(v) for v in M[:, r]]
+        n_new = sum(recv)
+        self.migrated = n_loc - send[r]
+        # migration: one all-to-all of 64-byte rows with exact sizes -- only of the bodies that change owner;
+        # the bodies that stay never move: arrivals take the vacated slots (csrc/slab.hip)
+        if W > 1:
+            send[r] = recv[r] = 0
+            n_leave, n_arrive = sum(send), sum(recv)
+            got = torch.empty((n_arrive, 16), dtype=torch.float32, device=dev)
+            dist.all_to_all_single(got, rows[:n_leave], output_split_sizes=recv, input_split_sizes=send,
+                                   group=self.group)
+            self._reserve(max(n_loc, n_new))
+            b.slab_fill(self._buf["posm"], self._buf["vel"], self._buf["acc"], self._buf["gid"], n_loc, holes, n_leave,
+                        got)
+            self._set_count(n_new)
+        bounds = lo + hi
+        if n_new:
+            b.grid_build("own", self.posm, bounds, self.cell, z_lo, z_hi - z_lo)
+        # halo: the rank's lowest layer goes to the owner of the layer below, its highest to the owner of the
+        # layer above; they are the head and the tail of the own grid's cell order
+        halo, work = None, None
+        if W > 1:
+            owner = layer_owner(gz, W)
+            s_split, r_split = [0] * W, [0] * W
+            n_head = n_tail = 0
+            if z_hi > z_lo:
+                if z_lo > 0:
+                    n_head = int(hist[z_lo])
+                    s_split[int(owner[z_lo - 1])] = n_head
+                    r_split[int(owner[z_lo - 1])] = int(hist[z_lo - 1])
+                if z_hi < gz:
+                    n_tail = int(hist[z_hi - 1])
+                    s_split[int(owner[z_hi])] = n_tail
+                    r_split[int(owner[z_hi])] = int(hist[z_hi])
+            out = torch.empty((n_head + n_tail, 4), dtype=torch.float32, device=dev)
+            if n_head:
+                b.grid_sorted("own", 0, n_head, out[:n_head])
+            if n_tail:
+                b.grid_sorted("own", n_new - n_tail, n_tail, out[n_head:])
+            halo = torch.empty((sum(r_split), 4), dtype=torch.float32, device=dev)
+            work = dist.all_to_all_single(halo, out, output_split_sizes=r_split, input_split_sizes=s_split,
+                                          group=self.group, async_op=True)
+        # own x own while the halo layers are in flight
+        acc_new = self._buf["acc2"][:n_new]
+        two_grid = True
+        if n_new:
+            two_grid = b.grid_forces("own", "own", z_lo, z_hi - z_lo, self.cutoff, self.G, self.eps, acc_new, False)
+        if work is not None:
+            work.wait()
+        self.halo_bodies = 0 if halo is None else int(halo.shape[0])
+        if n_new and two_grid and self.halo_bodies:
+            z0, z1 = max(z_lo - 1, 0), min(z_hi + 1, gz)
+            b.grid_build("halo", halo, bounds, self.cell, z0, z1 - z0)
+            for z in sorted({z_lo, z_hi - 1}):  # the boundary layers against the halo grid
+                two_grid = two_grid and b.grid_forces("own", "halo", z, 1, self.cutoff, self.G, self.eps, acc_new, True)
+        if n_new and not two_grid:  # too sparse for the per-cell start arrays: one grid over own + halo
+            allb = self.posm if not self.halo_bodies else torch.cat([self.posm, halo]).contiguous()
+            acc_new.copy_(b.hash_forces(allb, bounds, self.cell, self.cutoff, self.G, self.eps)[:n_new])
+        self.path = "two-grid" if two_grid else "one-grid"
+        self.acc_new = acc_new
+
+    def _global_grid(self):
+        return self._grid_from_bounds(self._global_box().cpu().numpy().tolist())
 
     # -- variable-size exchange: rows of `tensors` selected by `dest` go to their rank -----------
     def _exchange(self, tensors, dest):
@@ -404,7 +593,7 @@ class ShardedHashSystem:
         for t in tensors:
             if t.dtype == torch.float32:
                 c = t.reshape(t.shape[0], -1)
-            elif t.dtype == torch.int64:
+            elif t.dtype in (torch.int64, torch.int32):
                 c = t.to(torch.int32).view(torch.float32).reshape(t.shape[0], 1)  # ids < 2^31
             else:
                 raise TypeError(t.dtype)
@@ -424,15 +613,19 @@ class ShardedHashSystem:
         for dtype, tail, width in kinds:
             piece = dst[:, c0:c0 + width]
             c0 += width
-            if dtype == torch.int64:
-                out.append(piece.contiguous().view(torch.int32).reshape(-1).to(torch.int64))
+            if dtype in (torch.int64, torch.int32):
+                out.append(piece.contiguous().view(torch.int32).reshape(-1).to(dtype))
             else:
                 out.append(piece.reshape((dst.shape[0],) + tuple(tail)).contiguous())
         return out
 
-    def compute_forces(self):
+    def _compute_forces_generic(self, grid=None):
+        """The one-grid path (round 1): exchange first, then ONE build and ONE launch over [own; halo].
+        Generic torch selection ops and a host round trip per exchange; kept for very tall or very sparse
+        grids and for backends without the slab operations."""
         b = self.backend
-        lo, hi, dims = self._global_grid()
+        lo, hi, dims = grid if grid is not None else self._global_grid()
+        self.path = "one-grid"
         gz = dims[2]
         owner_np = layer_owner(gz, self.world)
         cz = b.cell_z(self.posm, lo[2], self.cell, gz).to(torch.int64) if self.posm.shape[0] else \
@@ -443,8 +636,8 @@ class ShardedHashSystem:
             dest = owner[cz]
             self.migrated = int((dest != self.rank).sum().item())
             # every rank takes part in the exchange even when nothing moves
-            self.posm, self.vel, self.acc, self.gid, cz = self._exchange(
-                [self.posm, self.vel, self.acc, self.gid, cz], dest)
+            posm, vel, acc, gid, cz = self._exchange([self.posm, self.vel, self.acc, self.gid, cz], dest)
+            self._replace(posm, vel, acc, gid)
             mine = np.nonzero(owner_np == self.rank)[0]
             send_rows, send_dest = [], []
             if mine.size:
@@ -465,17 +658,15 @@ class ShardedHashSystem:
             (halo,) = self._exchange([self.posm.index_select(0, rows)], hd)
             self.halo_bodies = int(halo.shape[0])
         n_loc = self.posm.shape[0]
+        self.acc_new = self._buf["acc2"][:n_loc]
         if n_loc == 0:
-            self.acc = torch.zeros((0, 4), dtype=torch.float32, device=self.device)
             return
         allb = self.posm if halo is None or halo.shape[0] == 0 else torch.cat([self.posm, halo]).contiguous()
-        acc_all = b.hash_forces(allb, lo + hi, self.cell, self.cutoff, self.G, self.eps)
-        self.acc_new = acc_all[:n_loc].contiguous()
+        self.acc_new.copy_(b.hash_forces(allb, lo + hi, self.cell, self.cutoff, self.G, self.eps)[:n_loc])
 
     def initial_forces(self):
         self.compute_forces()
-        if self.posm.shape[0]:
-            self.acc = self.acc_new
+        self._adopt_new_accelerations()
 
     def step(self, dt: float):
         b = self.backend
@@ -485,7 +676,7 @@ class ShardedHashSystem:
         self.compute_forces()
         if self.posm.shape[0]:
             b.kick(self.vel, self.acc, self.acc_new, dt)
-            self.acc = self.acc_new
+        self._adopt_new_accelerations()
 
     def gather_global(self):
         """(gid, posm, vel, acc) of all bodies on every rank, ordered by global id (test helper)."""

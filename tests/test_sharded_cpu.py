@@ -99,6 +99,109 @@ class OracleBackend:
         return torch.from_numpy(out)
 
 
+    # -- the slab operations of the overlapped two-grid step (numpy restatements of csrc/slab.hip and of
+    #    the two-grid force kernel; force sums by the oracle) ------------------------------------------
+    def _geometry(self, gbox, cell):
+        f = np.float32
+        lo = [f(gbox[a]) - f(0.001) for a in range(3)]
+        hi = [f(gbox[3 + a]) + f(0.001) for a in range(3)]
+        dims = [int(np.ceil((hi[a] - lo[a]) / f(cell))) + 1 for a in range(3)]
+        return lo, hi, dims
+
+    def slab_partition(self, posm, vel, acc, gid, gbox, cell, world, rank, hist_cap):
+        p, v, a, g = posm.numpy(), vel.numpy(), acc.numpy(), gid.numpy()
+        lo, _, dims = self._geometry(gbox.numpy(), cell)
+        gz = dims[2]
+        z = np.clip(np.floor((p[:, 2] - lo[2]) / np.float32(cell)).astype(np.int64), 0, gz - 1)
+        dest = ((z + 1) * world - 1) // gz
+        leave = np.nonzero(dest != rank)[0]                      # ascending = the vacated slots
+        order = leave[np.argsort(dest[leave], kind="stable")]   # rows: grouped by new owner, input order inside
+        rows = np.zeros((p.shape[0], 16), np.float32)
+        k = order.size
+        rows[:k, 0:4], rows[:k, 4:7], rows[:k, 8:11] = p[order], v[order, :3], a[order, :3]
+        rows[:k, 12] = g[order].astype(np.int32).view(np.float32)
+        rows[:k, 13] = z[order].astype(np.int32).view(np.float32)
+        holes = np.zeros(p.shape[0], np.int32)
+        holes[:k] = leave
+        stats = np.zeros(world * world + hist_cap, np.int32)
+        stats[rank * world:(rank + 1) * world] = np.bincount(dest, minlength=world)
+        if gz <= hist_cap:
+            stats[world * world:world * world + gz] = np.bincount(z, minlength=gz)
+        info = np.array([dims[0], dims[1], gz, int(gz > hist_cap)], np.int32)
+        return torch.from_numpy(rows), torch.from_numpy(holes), torch.from_numpy(stats), torch.from_numpy(info)
+
+    def slab_fill(self, posm, vel, acc, gid, n_old, holes, n_holes, arrivals):
+        # numpy restatement of slab_fill_kernel: arrivals into the holes in order, surplus appended, surplus
+        # holes closed with the bodies of the old tail (in order)
+        r = arrivals.numpy()
+        A, L = r.shape[0], n_holes
+        h = holes.numpy()[:L]
+        n_new = n_old - L + A
+        arrs = (posm.numpy(), vel.numpy(), acc.numpy())
+        g = gid.numpy()
+        slots = np.concatenate([h[:min(A, L)], np.arange(n_old, n_old + max(A - L, 0))]).astype(np.int64)
+        for arr, c0 in zip(arrs, (0, 4, 8)):
+            arr[slots] = 0
+            arr[slots, :4 if c0 == 0 else 3] = r[:, c0:c0 + (4 if c0 == 0 else 3)]
+        g[slots] = np.ascontiguousarray(r[:, 12]).view(np.int32)
+        if A < L:
+            tail = np.setdiff1d(np.arange(n_new, n_old), h)       # bodies of the old tail, ascending
+            to = h[A:A + tail.size]
+            assert tail.size == L - A - np.count_nonzero(h >= n_new) and np.all(to < n_new)
+            for arr in arrs:
+                arr[to] = arr[tail]
+            g[to] = g[tail]
+
+    def grid_build(self, slot, posm, bounds, cell, z_first, z_count):
+        p = posm.numpy().copy()
+        f = np.float32
+        dims = [int(np.ceil((f(bounds[3 + a]) - f(bounds[a])) / f(cell))) + 1 for a in range(3)]
+        c = [np.clip(np.floor((p[:, a] - f(bounds[a])) / f(cell)).astype(np.int64), 0, dims[a] - 1) for a in range(3)]
+        key = c[0] + c[1] * dims[0] + c[2] * dims[0] * dims[1]
+        assert np.all((c[2] >= z_first) & (c[2] < z_first + z_count))  # the slab promise of the caller
+        self.__dict__.setdefault("_grids", {})[slot] = dict(p=p, z=c[2], order=np.argsort(key, kind="stable"),
+                                                            bounds=list(bounds), dims=dims, cell=cell)
+
+    def grid_sorted(self, slot, first, count, out):
+        g = self._grids[slot]
+        out.numpy()[:count] = g["p"][g["order"][first:first + count]]
+
+    def grid_forces(self, slot_t, slot_s, z_first, z_count, cutoff, G, eps, acc_out, accumulate):
+        gt, gs = self._grids[slot_t], self._grids[slot_s]
+        assert gt["dims"] == gs["dims"] and gt["bounds"][:3] == gs["bounds"][:3]
+        sel = np.nonzero((gt["z"] >= z_first) & (gt["z"] < z_first + z_count))[0]
+        if sel.size == 0:
+            return True
+        t = gt["p"][sel]
+        if slot_t == slot_s:
+            others = np.ones(gt["p"].shape[0], bool)
+            others[sel] = False
+            src = np.concatenate([t, gt["p"][others]])          # targets first: they are sources too
+        else:
+            tz = t.copy()
+            tz[:, 3] = 0.0                                       # other grid: the targets exert nothing
+            src = np.concatenate([tz, gs["p"]])
+        c = np.ascontiguousarray
+        eps2 = float(np.float32(eps) * np.float32(eps))
+        a = np.stack(self.o.spatial_hash_forces_grid(c(src[:, 0]), c(src[:, 1]), c(src[:, 2]), c(src[:, 3]), sel.size,
+                                                     G, eps2, gt["cell"], cutoff, gt["bounds"][:3], gt["dims"]), 1)
+        o = acc_out.numpy()
+        if accumulate:
+            o[sel, :3] += a
+        else:
+            o[sel, :3] = a
+            o[sel, 3] = 0
+        return True
+
+    def to_host(self, *tensors):
+        return [t.numpy() for t in tensors]
+
+
+class GenericOracleBackend(OracleBackend):
+    """Without the slab operations: ShardedHashSystem takes its one-grid path."""
+    slab_partition = property()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -172,7 +275,7 @@ def test_shard_bounds(nb):
     assert shard_bounds(1 << 20, 8, 3) == (131072, 393216, 524288)
 
 
-def _hash_worker(rank, world, port, n, steps, cutoff, out_dir):
+def _hash_worker(rank, world, port, n, steps, cutoff, out_dir, generic=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -186,12 +289,14 @@ def _hash_worker(rank, world, port, n, steps, cutoff, out_dir):
         rng = np.random.default_rng(3)
         for k in ("vel_x", "vel_y", "vel_z"):
             ic[k] = rng.normal(0, 3.0, n).astype(np.float32)  # fast bodies: layers change owner
-        sysm = ShardedHashSystem(ic, 1.0, 0.05, 1.0, cutoff, backend=OracleBackend(), device="cpu")
+        sysm = ShardedHashSystem(ic, 1.0, 0.05, 1.0, cutoff, device="cpu",
+                                 backend=GenericOracleBackend() if generic else OracleBackend())
         sysm.initial_forces()
         moved = 0
         for _ in range(steps):
             sysm.step(0.02)
             moved += sysm.migrated
+        assert sysm.path == ("one-grid" if generic else "two-grid")
         gid, pos, vel, acc = sysm.gather_global()
         tot = torch.tensor([moved, sysm.halo_bodies], dtype=torch.int64)
         dist.all_reduce(tot)
@@ -202,13 +307,16 @@ def _hash_worker(rank, world, port, n, steps, cutoff, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cutoff", [(2, 1.0), (3, 1.0), (3, 2.0)])
-def test_sharded_hash_matches_single_process(tmp_path, world, cutoff, oracle, nb):
+@pytest.mark.parametrize("world,cutoff,generic", [(2, 1.0, False), (3, 1.0, False), (3, 2.0, False), (4, 1.0, False),
+                                                  (3, 2.0, True)])
+def test_sharded_hash_matches_single_process(tmp_path, world, cutoff, generic, oracle, nb):
     """z-slab shards + migration + halo exchange == the single-grid run (the reference semantics,
-    including the pairs its 27-cell search misses when cutoff > cell)."""
+    including the pairs its 27-cell search misses when cutoff > cell); overlapped two-grid step and the
+    one-grid fallback."""
     from oracle_bind import host_state
     n, steps, dt, eps = 1500, 3, 0.02, 0.05
-    mp.spawn(_hash_worker, args=(world, _free_port(), n, steps, cutoff, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_hash_worker, args=(world, _free_port(), n, steps, cutoff, str(tmp_path), generic), nprocs=world,
+             join=True)
     got = np.load(tmp_path / f"h{world}.npz")
     assert np.array_equal(got["gid"], np.arange(n))      # every body exactly once
     assert got["moved"] > 0 and got["halo"] > 0           # migration and halos were exercised

@@ -93,6 +93,7 @@ def _hash_worker(rank, world, port, n, steps, cutoff, out_dir):
         for _ in range(steps):
             sysm.step(0.02)
             moved += sysm.migrated
+        assert sysm.path == "two-grid"  # the overlapped step, not the one-grid fallback
         gid, pos, vel, acc = sysm.gather_global()
         tot = torch.tensor([moved, sysm.halo_bodies], dtype=torch.int64)
         dist.all_reduce(tot)

@@ -206,9 +206,81 @@ def test_packed_slabs_equal_whole(nb, oracle, ctx, cutoff):
         nz = np.linalg.norm(whole[own], axis=1) > 0
         assert rel_err(acc[nz], whole[own][nz]).max() < TOL  # summation order differs per slab
         assert np.all(acc[~nz] == 0)
+        # the overlapped form: own x own on the slab's grid, then its two boundary layers against a grid
+        # of the halo layers, accumulated (nbody_hip_grid_forces_pair_packed); cell order of the own grid
+        # starts with the lowest and ends with the highest layer (what the halo exchange sends)
+        z0, z1 = int(layers[0]), int(layers[-1]) + 1
+        own_t = p[torch.from_numpy(own).cuda()].contiguous()
+        halo_t = p[torch.from_numpy(halo).cuda()].contiguous()
+        be.grid_build("own", own_t, lo + hi, cell, z0, z1 - z0)
+        acc2 = torch.full((own.size, 4), 7.0, device="cuda")
+        assert be.grid_forces("own", "own", z0, z1 - z0, cutoff, G, eps, acc2, False)
+        if halo.size:
+            be.grid_build("halo", halo_t, lo + hi, cell, max(z0 - 1, 0), min(z1 + 1, dims[2]) - max(z0 - 1, 0))
+            for z in sorted({z0, z1 - 1}):
+                assert be.grid_forces("own", "halo", z, 1, cutoff, G, eps, acc2, True)
+        a2 = acc2.cpu().numpy()
+        assert np.all(a2[:, 3] == 0)
+        assert rel_err(a2[nz, :3], whole[own][nz]).max() < TOL
+        n_head, n_tail = int((cz[own] == z0).sum()), int((cz[own] == z1 - 1).sum())
+        head = torch.empty((n_head, 4), device="cuda")
+        tail = torch.empty((n_tail, 4), device="cuda")
+        be.grid_sorted("own", 0, n_head, head)
+        be.grid_sorted("own", own.size - n_tail, n_tail, tail)
+        cz_of = lambda t: np.clip(np.floor((t.cpu().numpy()[:, 2] - np.float32(lo[2])) / np.float32(cell)), 0, dims[2] - 1)  # noqa: E731
+        assert np.all(cz_of(head) == z0) and np.all(cz_of(tail) == z1 - 1)
+    # the partition pass (csrc/slab.hip) against its numpy restatement: rows grouped by owner in input
+    # order, send-matrix row, layer histogram, grid size
+    W, rk = 4, 1
+    vel = torch.from_numpy(np.random.default_rng(1).normal(size=(n, 4)).astype(np.float32)).cuda()
+    acc0 = torch.from_numpy(np.random.default_rng(2).normal(size=(n, 4)).astype(np.float32)).cuda()
+    gid = torch.arange(n, dtype=torch.int32, device="cuda") * 3
+    rows, holes, stats, info = be.slab_partition(p, vel, acc0, gid, torch.from_numpy(bb).cuda(), cell, W, rk, 4096)
+    rows, holes, stats, info = rows.cpu().numpy(), holes.cpu().numpy(), stats.cpu().numpy(), info.cpu().numpy()
+    assert list(info) == [dims[0], dims[1], dims[2], 0]
+    dest = owner[cz]
+    leave = np.nonzero(dest != rk)[0]
+    order = leave[np.argsort(dest[leave], kind="stable")]
+    L = leave.size
+    assert 0 < L < n
+    assert np.array_equal(stats[rk * W:(rk + 1) * W], np.bincount(dest, minlength=W))
+    assert stats[:W * W].sum() == n
+    assert np.array_equal(stats[W * W:W * W + dims[2]], np.bincount(cz, minlength=dims[2]))
+    assert stats[W * W + dims[2]:].sum() == 0
+    pn, vn, an = p.cpu().numpy(), vel.cpu().numpy(), acc0.cpu().numpy()
+    assert np.array_equal(holes[:L], leave)
+    assert np.array_equal(rows[:L, 0:4], pn[order])
+    assert np.array_equal(rows[:L, 4:7], vn[order, :3]) and np.all(rows[:L, 7] == 0)
+    assert np.array_equal(rows[:L, 8:11], an[order, :3])
+    assert np.array_equal(rows[:L, 12].view(np.int32), 3 * order) and np.array_equal(rows[:L, 13].view(np.int32), cz[order])
+    # the fill pass: fewer, equally many and more arrivals than vacated slots
+    rng = np.random.default_rng(5)
+    for A in (L // 3, L, L + 1000, 0):
+        arr = rng.normal(size=(A, 16)).astype(np.float32)
+        arr[:, 12] = (np.arange(A, dtype=np.int32) + 10 ** 6).view(np.float32)
+        cap = n + 2000
+        bufs = [torch.zeros((cap, 4), device="cuda") for _ in range(3)]
+        for t, src in zip(bufs, (pn, vn, an)):
+            t[:n] = torch.from_numpy(src).cuda()
+        gbuf = torch.zeros(cap, dtype=torch.int32, device="cuda")
+        gbuf[:n] = gid
+        be.slab_fill(bufs[0], bufs[1], bufs[2], gbuf, n, torch.from_numpy(holes).cuda(), L, torch.from_numpy(arr).cuda())
+        n_new = n - L + A
+        got_ids = gbuf[:n_new].cpu().numpy()
+        keep = np.setdiff1d(np.arange(n), leave)
+        assert np.array_equal(np.sort(got_ids), np.sort(np.concatenate([3 * keep, np.arange(A) + 10 ** 6])))  # a permutation
+        gp, gv = bufs[0][:n_new].cpu().numpy(), bufs[1][:n_new].cpu().numpy()
+        stay = got_ids < 10 ** 6
+        assert np.array_equal(gp[stay], pn[got_ids[stay] // 3]) and np.array_equal(gv[stay], vn[got_ids[stay] // 3])
+        came = got_ids[~stay] - 10 ** 6
+        assert np.array_equal(gp[~stay], arr[came, 0:4]) and np.array_equal(gv[~stay][:, :3], arr[came, 4:7])
+        # bodies that stayed below the new end did not move
+        low = keep[keep < n_new]
+        assert np.array_equal(got_ids[low], 3 * low)
     # world-1 system: a full step equals Integrator.integrate with the SoA calculator
     sysm.initial_forces()
     sysm.step(1e-3)
+    assert sysm.path == "two-grid"
     integ = nb.Integrator()
     integ.integrate(d, calc, 1e-3)
     gid, pos, vel, acc = sysm.gather_global()
