@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane override")
     ap.add_argument("--splits", type=int, default=0, help="source splits override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="Direct: slot planes + fixed-order sums instead of fp64 atomics (bitwise reproducible)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the Barnes-Hut / spatial-hash / general-mass objects appended to the default run")
     ap.add_argument("--workload", choices=["direct", "hash", "bh"], default="direct",
@@ -350,6 +352,8 @@ def main():
     ctx = nb.default_context(local_rank)
     if a.variant >= 0 or a.tpl or a.splits:
         ctx.tuning(a.variant, a.tpl, a.splits)
+    if a.deterministic:
+        ctx.deterministic(True)
 
     n = a.n
     G, eps, dt = 1.0, a.eps, a.dt
@@ -416,7 +420,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"plummer_N{n}_direct_n2_velocity_verlet", "bodies": n,
-                       "eps": eps, "dt": dt, "G": G, "seed": 42, "path": path,
+                       "eps": eps, "dt": dt, "G": G, "seed": 42, "path": path, "deterministic": bool(a.deterministic),
                        "sharding": f"targets_by_index_range_x{world}"},
         }
         # --- roofline of the dominant kernel, timed live with HIP events on the launch stream

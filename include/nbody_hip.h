@@ -322,6 +322,11 @@ NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int 
  * atomic per wave in every walk). */
 NBODY_HIP_API int nbody_hip_tree_count_visits(nbody_hip_tree* tree, int enable);
 
+/* Diagnostics of the last walk made with visit counting on: out[p] (p = 0..64) = internal-node tests made
+ * with p lanes of the wave taking part, out[65 + q] = with q lanes accepting the node's monopole.
+ * Blocking. */
+NBODY_HIP_API int nbody_hip_tree_visit_histogram(nbody_hip_tree* tree, unsigned long long out[130]);
+
 /* ref: BarnesHutTree(max_particles) :204-210 */
 NBODY_HIP_API int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, nbody_hip_tree** out);
 NBODY_HIP_API int nbody_hip_tree_destroy(nbody_hip_tree* tree);
@@ -366,6 +371,16 @@ NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_f
                                  size_t n_targets, const nbody_float4* sources, size_t n_sources,
                                  nbody_float4* acc_out, float G, float eps2, int iters,
                                  float* ms_per_launch);
+
+/* Direct forces are bitwise reproducible at every size, like the reference's one-thread-per-body loop
+ * (ref: force_direct.cu:10-85): in the symmetric (action = -reaction) kernel every contribution to a body
+ * goes to a slot of its own and the slots are added in a fixed order.  enable = 0 switches to fp64 atomics
+ * instead (their order varies from launch to launch: fp32 results differ in the last bit now and then).
+ * The slots cost 24 (N / (512 R) + splits) bytes per body of workspace (3.4 GB at N = 2^20) and 0.5 % of
+ * time (measured: 156.2 vs 155.4 ms per step at N = 2^20); above 24 GiB of slots (N > ~2.7 M) the atomic
+ * form is used regardless.  The one-sided kernel (N < 12,288, rectangular sets) is reproducible anyway; the
+ * two-set kernel of the sharded path keeps its atomics.  On by default. */
+NBODY_HIP_API int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int enable);
 
 /* Tuning knobs for experiments.  variant: -1 automatic, 0 scalar body + LDS sources, 1 packed
  * (v_pk_*_f32) body + LDS sources, 2 scalar body + scalar-cache sources, 3 symmetric (action =

@@ -113,6 +113,7 @@ PROTOTYPES = {
     "nbody_hip_tree_destroy": (C.c_int, [_P]),
     "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_tree_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
+    "nbody_hip_tree_visit_histogram": (C.c_int, [_P, C.POINTER(C.c_ulonglong * 130)]),
     "nbody_hip_tree_count_visits": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_build": (C.c_int, [_P, _PD]),
     "nbody_hip_tree_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
@@ -123,6 +124,7 @@ PROTOTYPES = {
     "nbody_hip_tree_copy_nodes": (C.c_int, [_P, _P, C.c_int, _P]),
     "nbody_hip_time_direct_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_float,
                                                C.c_float, C.c_int, C.POINTER(C.c_float)]),
+    "nbody_hip_direct_deterministic": (C.c_int, [_P, C.c_int]),
     "nbody_hip_direct_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
 }
 

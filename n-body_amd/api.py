@@ -145,6 +145,10 @@ class Context:
     def tuning(self, variant=-1, targets_per_lane=0, source_splits=0):
         check(self._lib.nbody_hip_direct_tuning(self._h, variant, targets_per_lane, source_splits))
 
+    def deterministic(self, enable: bool = True):
+        """Direct forces bitwise reproducible at every size (nbody_hip_direct_deterministic)."""
+        check(self._lib.nbody_hip_direct_deterministic(self.handle, 1 if enable else 0))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.nbody_hip_ctx_destroy(self._h)

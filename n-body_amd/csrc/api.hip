@@ -378,6 +378,12 @@ extern "C" int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_floa
   return NBODY_HIP_OK;
 }
 
+extern "C" int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int enable) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  ctx->deterministic = enable != 0;
+  return NBODY_HIP_OK;
+}
+
 extern "C" int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
                                        int source_splits) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");

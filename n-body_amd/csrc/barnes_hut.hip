@@ -384,6 +384,8 @@ __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __re
   t.rec[nid] = r;
 }
 
+constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; [66..130] by lanes accepting
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // |d|^2 of the walk: dx*dx, then two fused multiply-adds -- the chain nvcc's default contraction makes
@@ -501,15 +503,23 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       // :171-172 `size2 / dist2 < theta2`, evaluated as size2 < theta2 * dist2 (dist2 > 0): the same
       // inequality without the IEEE division sequence; the oracle uses the same form
       const bool far = nd.size2 < theta2 * dist2;
+      const unsigned long long F = __ballot(far);
+      if (visit_count) {  // diagnostics (nbody_hip_tree_count_visits): lanes that test / accept this node
+        if (lane == 0) {
+          atomicAdd(&visit_count[1 + __popcll(M)], 1ull);
+          atomicAdd(&visit_count[66 + __popcll(M & F)], 1ull);
+        }
+      }
       {  // one select on the factor; a masked region is if-converted by the compiler into three selects on
-         // the sums anyway (measured: -4..8 % against `if (in && far && mine) {...}`)
+         // the sums anyway (measured: -4..8 % against `if (in && far && mine) {...}`; skipping the block
+         // with a wave-uniform branch when no lane accepts: no gain, round 2)
         const float inv = __builtin_amdgcn_rsqf(dist2);
         const float f = (in && far && mine) ? ((nd.mass * inv) * inv) * inv : 0.f;
         ax = __builtin_fmaf(f, dx, ax); ay = __builtin_fmaf(f, dy, ay); az = __builtin_fmaf(f, dz, az);
       }
       // lanes of the group's mask that must open the node: scalar mask arithmetic on the compare
       // result (a ballot of `in && !far` goes through a VGPR and a second compare)
-      const unsigned long long O = M & ~__ballot(far);
+      const unsigned long long O = M & ~F;
       if (O != 0ull) {
         if (lane == 0)
           stk[w][sp] = make_int4((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28) | (shared ? 256 : 0),
@@ -652,7 +662,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   const size_t nflag = (size_t)(kMaxDepth + 1) * n;
   if (e == hipSuccess) e = dmalloc(&g->d_flag, nflag);
   if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
-  if (e == hipSuccess) e = dmalloc(&g->d_visits, 1);
+  if (e == hipSuccess) e = dmalloc(&g->d_visits, kVisitWords);
   if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
   if (e == hipSuccess) e = dmalloc(&g->d_prefix, (size_t)kPrefixMax + 1);
   if (e == hipSuccess) {
@@ -796,7 +806,7 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   const int blocks = (n + kBlock - 1) / kBlock;
   const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
   unsigned long long* visits = g->count_visits ? g->d_visits : nullptr;
-  if (visits) NBH_HIP(hipMemsetAsync(visits, 0, sizeof(unsigned long long), ctx->stream));
+  if (visits) NBH_HIP(hipMemsetAsync(visits, 0, kVisitWords * sizeof(unsigned long long), ctx->stream));
   if (n == 0) return NBODY_HIP_OK;
   // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
   int K = 1;
@@ -854,8 +864,17 @@ extern "C" int nbody_hip_tree_count_visits(nbody_hip_tree* g, int enable) {
   g->count_visits = enable != 0;
   if (!g->count_visits) {
     NBH_HIP(hipSetDevice(g->ctx->device));
-    NBH_HIP(hipMemsetAsync(g->d_visits, 0, sizeof(unsigned long long), g->ctx->stream));
+    NBH_HIP(hipMemsetAsync(g->d_visits, 0, kVisitWords * sizeof(unsigned long long), g->ctx->stream));
   }
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_visit_histogram(nbody_hip_tree* g, unsigned long long out[130]) {
+  if (!g || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  NBH_NOT_CAPTURABLE(g->ctx, "tree inspection");
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  NBH_HIP(hipStreamSynchronize(g->ctx->stream));
+  NBH_HIP(hipMemcpy(out, g->d_visits + 1, 130 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return NBODY_HIP_OK;
 }
 

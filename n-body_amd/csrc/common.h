@@ -78,6 +78,7 @@ struct nbody_hip_ctx {
   mutable bool capture_failed = false;           // a non-capturable call was made while recording
   // tuning overrides (variant -1 / others 0 = automatic)
   int tune_variant = -1, tune_tpl = 0, tune_splits = 0;
+  bool deterministic = true;   // symmetric all-pairs kernel: slot planes + fixed-order sum instead of fp64 atomics
   // bumped when a tree / grid of this context re-sizes or frees device arrays a recorded step graph
   // may point into; together with the workspaces' generations it dates a recording
   unsigned long long alloc_generation = 0;

@@ -55,9 +55,15 @@ __device__ __forceinline__ float wave_rot1(float v) {
 #endif
 constexpr int kSymBlocksPerCU = 16;  // workgroups aimed at per CU (tools/sweep_mid.py)
 constexpr int kSymMinChunks = 4;     // at least 4 chunks (256 J bodies) per workgroup
+constexpr size_t kDetBudgetBytes = (size_t)24 << 30;  // slot planes of the deterministic mode: at most 24 GiB
 constexpr float kFar = 1.0e18f;  // padding bodies sit here: (3e36)^-3/2 underflows to 0, no mass test needed
 
-template <int R, bool RECT, bool EQM>
+// DET (all-pairs form only): deterministic sums.  Instead of fp64 atomics every contribution gets a slot
+// of its own -- the reaction of the partner at ring offset d goes to slot d - 1 of the receiving body,
+// the I-side sum of split s to slot D + s -- written once with plain (coalesced) stores; the finalize
+// kernel adds a body's slots in a fixed order.  Bitwise reproducible like the reference's one-thread-
+// per-body loop (force_direct.cu:10-85) at the price of 12 N^2 / S bytes of slot planes.
+template <int R, bool RECT, bool EQM, bool DET = false>
 __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const float4* __restrict__ posm, int n,
                                                             const float4* __restrict__ posj, int nj,
                                                             int NB, int NBJ, int chunks_per_split,
@@ -82,7 +88,16 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
   constexpr int CPB = kBlock * R / 64;
   const int q0 = blockIdx.y * chunks_per_split;
   const int q1 = min((D + 1) * CPB, q0 + chunks_per_split);
-  if (q0 >= q1) return;
+  if (q0 >= q1) {
+    if constexpr (DET) {  // an empty share still owns an I-side slot: it must read as zero
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          acc64[((size_t)(D + blockIdx.y) * 3 + c) * plane_i + (size_t)(A * S + r * kBlock + tid)] = 0.0;
+    }
+    return;
+  }
 
   // I side: R bodies per lane, packed in pairs
   f2 xi[R / 2], yi[R / 2], zi[R / 2], mi[R / 2];
@@ -130,7 +145,18 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
   };
   auto flush_chunk = [&](int q) {  // one wave: combine the four waves' sums of chunk q, add to global
     const int pd = (q0 + q) / CPB, pc = (q0 + q) % CPB;
-    if ((RECT || pd > 0) && partner_valid(pd)) {
+    if constexpr (DET) {
+      if (pd > 0) {  // slot pd - 1 of the partner's bodies; a partner the half ring skips contributes zero
+        const int j = ((A + pd) % NB) * S + pc * 64 + lane;
+        const int sb = q & 1;
+        const bool ok = partner_valid(pd);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float v = (slab[sb][0][c][lane] + slab[sb][1][c][lane]) + (slab[sb][2][c][lane] + slab[sb][3][c][lane]);
+          acc64[((size_t)(pd - 1) * 3 + c) * plane_i + (size_t)j] = ok ? (double)v * (double)m0 : 0.0;
+        }
+      }
+    } else if ((RECT || pd > 0) && partner_valid(pd)) {
       const int j = (RECT ? pd : (A + pd) % NB) * S + pc * 64 + lane;
       const int sb = q & 1;
       double* dst = RECT ? accj64 : acc64;
@@ -225,9 +251,16 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
     const double fx = LACC ? lacc[(0 * R + r) * kBlock + tid] : sx[LACC ? 0 : r];
     const double fy = LACC ? lacc[(1 * R + r) * kBlock + tid] : sy[LACC ? 0 : r];
     const double fz = LACC ? lacc[(2 * R + r) * kBlock + tid] : sz[LACC ? 0 : r];
-    unsafeAtomicAdd(&acc64[(size_t)i], fx * (double)m0);
-    unsafeAtomicAdd(&acc64[plane_i + (size_t)i], fy * (double)m0);
-    unsafeAtomicAdd(&acc64[2 * plane_i + (size_t)i], fz * (double)m0);
+    if constexpr (DET) {
+      double* slot = acc64 + (size_t)(D + blockIdx.y) * 3 * plane_i;
+      slot[(size_t)i] = fx * (double)m0;
+      slot[plane_i + (size_t)i] = fy * (double)m0;
+      slot[2 * plane_i + (size_t)i] = fz * (double)m0;
+    } else {
+      unsafeAtomicAdd(&acc64[(size_t)i], fx * (double)m0);
+      unsafeAtomicAdd(&acc64[plane_i + (size_t)i], fy * (double)m0);
+      unsafeAtomicAdd(&acc64[2 * plane_i + (size_t)i], fz * (double)m0);
+    }
   }
 }
 
@@ -261,14 +294,18 @@ __global__ __launch_bounds__(kBlock) void mass_range_kernel(const float4* __rest
 
 // acc = G * acc64 ; SoA or float4 output ; optional fused Velocity-Verlet kick
 __global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
-    const double* __restrict__ acc64, size_t plane, int n, float G, float4* __restrict__ acc4, int accumulate,
+    const double* __restrict__ acc64, size_t plane, int nslots, int n, float G, float4* __restrict__ acc4, int accumulate,
     float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, float* __restrict__ vx,
     float* __restrict__ vy, float* __restrict__ vz, const float* __restrict__ aox,
     const float* __restrict__ aoy, const float* __restrict__ aoz, float half_dt) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const float fx = (float)((double)G * acc64[i]), fy = (float)((double)G * acc64[plane + i]),
-              fz = (float)((double)G * acc64[2 * plane + i]);
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int k = 0; k < nslots; k++) {  // one slot with atomics; the deterministic mode's slots in a fixed order
+    const double* p = acc64 + (size_t)k * 3 * plane;
+    sx += p[i]; sy += p[plane + i]; sz += p[2 * plane + i];
+  }
+  const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
   if (acc4) {
     float4 o = make_float4(fx, fy, fz, 0.f);
     if (accumulate) { const float4 c = acc4[i]; o.x += c.x; o.y += c.y; o.z += c.z; }
@@ -294,8 +331,17 @@ static void launch_mass_range(nbody_hip_ctx* ctx, const float4* pi, int ni, cons
 template <int R, bool RECT>
 static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, const float4* pj, int nj,
                        int NB, int NBJ, int per, double* acci, double* accj, const unsigned int* enc,
-                       float eps2) {
+                       float eps2, bool det = false) {
   const size_t S = (size_t)kBlock * R;
+  if constexpr (!RECT) {
+    if (det) {
+      hipLaunchKernelGGL((direct_sym_kernel<R, false, true, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
+                         NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
+      hipLaunchKernelGGL((direct_sym_kernel<R, false, false, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
+                         NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
+      return;
+    }
+  }
   // both instantiations are queued; the one whose mass assumption does not hold exits at once
   hipLaunchKernelGGL((direct_sym_kernel<R, RECT, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
                      NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
@@ -337,26 +383,32 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
   if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);  // whole partners when there are enough
   splits = (total + per - 1) / per;
   const size_t plane = (size_t)NB * S;
-  const size_t acc_bytes = plane * 3 * sizeof(double);  // three component planes
+  // deterministic mode: one slot per contribution (D reaction slots + one I-side slot per split); every
+  // slot is written exactly once by the kernel, so nothing has to be cleared.  It needs 24 (D + splits)
+  // bytes per body: taken when asked for (nbody_hip_direct_deterministic) and it fits the budget
+  const int nslots_det = D + splits;
+  const bool det = ctx->deterministic && (size_t)nslots_det * plane * 3 * sizeof(double) <= kDetBudgetBytes;
+  const int nslots = det ? nslots_det : 1;
+  const size_t acc_bytes = (size_t)nslots * plane * 3 * sizeof(double);  // three component planes per slot
   if (int rc = ctx->partial.reserve(acc_bytes)) return rc;
   double* acc64 = static_cast<double*>(ctx->partial.ptr);
-  NBH_HIP(hipMemsetAsync(acc64, 0, acc_bytes, ctx->stream));
+  if (!det) NBH_HIP(hipMemsetAsync(acc64, 0, acc_bytes, ctx->stream));
   if (int rc = ctx->reduce.reserve(64)) return rc;
   unsigned int* enc = static_cast<unsigned int*>(ctx->reduce.ptr);
   const dim3 grid(NB, splits);
   const int ni = (int)n;
   launch_mass_range(ctx, posm, ni, posm, ni, enc);
   switch (R) {
-    case 2: launch_sym<2, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
-    case 6: launch_sym<6, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
-    case 8: launch_sym<8, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
-    case 16: launch_sym<16, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
-    default: launch_sym<4, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2); break;
+    case 2: launch_sym<2, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
+    case 6: launch_sym<6, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
+    case 8: launch_sym<8, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
+    case 16: launch_sym<16, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
+    default: launch_sym<4, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
   }
   NBH_LAUNCH_CHECK();
   const int fblocks = (int)((n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, acc64,
-                     plane, ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
+                     plane, nslots, ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
@@ -394,10 +446,10 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
   }
   NBH_LAUNCH_CHECK();
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((ni + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, acci, plane_i, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
+                     ctx->stream, acci, plane_i, 1, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((nj + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, accj, plane_j, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
+                     ctx->stream, accj, plane_j, 1, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;

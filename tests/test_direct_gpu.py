@@ -379,3 +379,65 @@ def test_pair_mode_contributions_sum_to_whole(nb, ctx, W):
         total += c
     got = total[:n].cpu().numpy()[:, :3]
     assert rel_err(got, whole).max() < TOL
+
+
+# nbody_hip_direct_deterministic: the symmetric kernel with one slot per contribution and a fixed-order
+# sum instead of fp64 atomics -- bitwise reproducible like the reference's one-thread-per-body loop
+# (ref: force_direct.cu:10-85), same values as the atomic form to fp64 rounding of the sums
+@pytest.mark.parametrize("n,tpl,equal_mass", [(13000, 0, True), (40000, 2, False), (70000, 6, True), (100003, 8, False),
+                                              (90001, 16, True), (262144, 0, False)])
+def test_deterministic_symmetric_kernel(nb, oracle, ctx, n, tpl, equal_mass):
+    ic = nb.ic.plummer(n, seed=n + 1)
+    if not equal_mass:
+        ic["mass"] = (ic["mass"] * np.random.default_rng(n).uniform(0.2, 3.0, n)).astype(np.float32)
+    p = packed(ic)
+    eps2 = 1e-6
+    try:
+        ctx.tuning(3 if tpl else -1, tpl, 0)
+        plain = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+        ctx.deterministic(True)
+        a = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+        b = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+        c = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+    finally:
+        ctx.deterministic(False)
+        ctx.tuning()
+    assert torch.equal(a, b) and torch.equal(a, c)  # bit for bit, launch after launch
+    assert rel_err(a.cpu().numpy()[:, :3], plain.cpu().numpy()[:, :3]).max() < 1e-6
+    rng = np.random.default_rng(1)
+    idx = np.unique(np.concatenate([rng.choice(n, 768, replace=False), np.arange(n - 200, n), np.arange(200)]))
+    ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
+                                                1.0, eps2, 1), 1)
+    assert rel_err(a.cpu().numpy()[idx, :3], ref).max() < TOL
+    assert torch.all(a[:, 3] == 0)
+
+
+# ... and through the drop-in path: a Direct ParticleSystem-style run continues bit for bit after a
+# save / load of its state (the pause / resume property, tests/test_serialization.cpp:171-216, at a size
+# where the symmetric kernel is the default)
+def test_deterministic_direct_save_load_continue(nb, ctx):
+    n = 40000
+    ic = nb.ic.plummer(n, seed=8)
+    fc = nb.DirectForceCalculator()
+    fc.setSofteningParameter(0.01)
+    integ = nb.Integrator()
+
+    def run(split):
+        d, _ = to_device(nb, ic)
+        fc.computeForces(d)
+        for _ in range(split):
+            integ.integrate(d, fc, 1e-3)
+        if split < 4:  # "save": positions, velocities, masses only; accelerations are recomputed on load
+            state = {k: getattr(d, k).cpu().numpy().copy() for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
+            d, _ = to_device(nb, state)
+            fc.computeForces(d)
+            for _ in range(4 - split):
+                integ.integrate(d, fc, 1e-3)
+        return np.stack([getattr(d, k).cpu().numpy() for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z")])
+
+    try:
+        ctx.deterministic(True)
+        whole, resumed = run(4), run(2)
+    finally:
+        ctx.deterministic(False)
+    assert np.array_equal(whole, resumed)

@@ -311,22 +311,23 @@ def test_integrate_calls_a_subclass_override(nb, ctx):
 # the old buffers are freed: replaying must be refused (NBODY_HIP_ERR_STATE), not touch freed memory;
 # Integrator.integrate_steps records again by itself.
 def test_stale_step_graph_is_refused_and_rerecorded(nb, ctx):
+    own = nb.Context()  # a context of its own: the shared default context's workspaces are already large
     small = nb.ic.plummer(3000, seed=1)
     d, _ = to_device(nb, small)
-    fc = nb.DirectForceCalculator()
+    fc = nb.DirectForceCalculator(ctx=own)
     fc.setSofteningParameter(0.05)
-    integ = nb.Integrator()
+    integ = nb.Integrator(ctx=own)
     fc.computeForces(d)
     integ.integrate_steps(d, fc, 1e-3, 3, graph=True)
     old = integ._graph
     assert old is not None
-    # a system 100x larger on the same (default) context re-allocates posm / partial
+    # a system 100x larger on the same context re-allocates posm / partial
     big = nb.ic.plummer(300000, seed=2)
     d2, _ = to_device(nb, big)
-    fc2 = nb.DirectForceCalculator()
+    fc2 = nb.DirectForceCalculator(ctx=own)
     fc2.setSofteningParameter(0.05)
     fc2.computeForces(d2)
-    ctx.synchronize()
+    own.synchronize()
     with pytest.raises(nb.StateException, match="stale"):
         old.launch(1)
     # the high-level call recovers: same trajectory as an eager run from the same state
@@ -336,14 +337,14 @@ def test_stale_step_graph_is_refused_and_rerecorded(nb, ctx):
         getattr(ref, k).copy_(getattr(d, k))
     integ.integrate_steps(d, fc, 1e-3, 3, graph=True)
     assert integ._graph is not old
-    nb.Integrator().integrate_steps(ref, fc, 1e-3, 3, graph=False)
+    nb.Integrator(ctx=own).integrate_steps(ref, fc, 1e-3, 3, graph=False)
     for k in ("pos_x", "vel_y", "acc_z"):
         assert torch.equal(getattr(d, k), getattr(ref, k)), k
     # a tree re-sized after the recording
-    bh = nb.BarnesHutCalculator(0.5)
+    bh = nb.BarnesHutCalculator(0.5, ctx=own)
     bh.setSofteningParameter(0.05)
     bh.computeForces(d)
-    integ2 = nb.Integrator()
+    integ2 = nb.Integrator(ctx=own)
     integ2.integrate_steps(d, bh, 1e-3, 2, graph=True)
     g = integ2._graph
     bh.getTree().setParams(8, 4)
