@@ -330,10 +330,12 @@ NBODY_HIP_API int nbody_hip_tree_visit_histogram(nbody_hip_tree* tree, unsigned 
 /* ref: BarnesHutTree(max_particles) :204-210 */
 NBODY_HIP_API int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, nbody_hip_tree** out);
 NBODY_HIP_API int nbody_hip_tree_destroy(nbody_hip_tree* tree);
-/* Tree shape: levels below the root (1..10, default 10 = 30-bit Morton keys; the reference caps
- * its insertion at depth 20, :363) and the largest body count a leaf may hold (default 1, as in
- * the reference, where a leaf holds one particle; at the deepest level a leaf keeps whatever
- * falls into its cell).  Re-sizes the node arrays; the tree must be rebuilt afterwards. */
+/* Tree shape: levels below the root (1..21; default 20, the depth the reference's insertion loop stops
+ * at, :363) and the largest body count a leaf may hold (default 1, as in the reference, where a leaf
+ * holds one particle; at the deepest level a leaf keeps whatever falls into its cell).  Up to 10 levels
+ * the bodies are ordered by the reference's 30-bit Morton code (:23-38) in 32-bit keys; deeper trees use
+ * 63-bit keys (21 bits per axis, a refinement of the same grid).  Re-sizes the key, flag and node arrays;
+ * the tree must be rebuilt afterwards. */
 NBODY_HIP_API int nbody_hip_tree_set_params(nbody_hip_tree* tree, int max_depth, int leaf_max);
 /* ref: BarnesHutTree::build :282-289 -- bounding box, Morton keys, sort, octree, monopoles; all on
  * the device, no host round trip (the reference crosses PCIe >= 17 times here). */

@@ -628,7 +628,7 @@ class BarnesHutTree:
         except Exception:
             pass
 
-    def setParams(self, max_depth: int = 10, leaf_max: int = 1):
+    def setParams(self, max_depth: int = 20, leaf_max: int = 1):
         check(self.ctx._lib.nbody_hip_tree_set_params(self._h, max_depth, leaf_max))
         self._params = (int(max_depth), int(leaf_max))
 

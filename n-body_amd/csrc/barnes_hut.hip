@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -46,7 +47,12 @@ namespace nbh {
 #define NBH_BH_XCD 1
 #endif
 
-constexpr int kMaxDepth = 10;      // 30-bit Morton keys
+constexpr int kMaxDepth = 21;      // 63-bit Morton keys (the reference caps its insertion at depth 20, :363)
+constexpr int kDepth32 = 10;       // up to here 30-bit keys in 32-bit words (the faster sort)
+constexpr int kDefaultDepth = 20;  // the depth the reference's insertion loop stops at (:363).  Measured at
+                                   // N = 2^20 (tools/bh_depth_sweep.py): build 0.41 -> 0.65 ms against depth 10, walk
+                                   // unchanged for the BASELINE bodies -- and 90 -> 3.6 ms for a compact Plummer core
+                                   // (a = 0.1), whose depth-10 cells hold up to 1,600 bodies
 constexpr int kStack = 8 * (kMaxDepth + 2);
 constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
 constexpr int kSplitAuto = 262144;     // automatic choice: replicas * n up to here (= 4096 waves)
@@ -83,20 +89,52 @@ __device__ __forceinline__ unsigned int expand_bits10(unsigned int v) {  // :23-
   return v;
 }
 
+// 21 bits -> every third bit of a 64-bit word
+__device__ __forceinline__ unsigned long long expand_bits21(unsigned long long v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// Key word and bits per axis: 10 bits per axis in 32-bit keys (max_depth <= 10), 21 bits per axis in
+// 64-bit keys beyond.  The finer keys REFINE the coarser ones: the cube is cut into 2^B cells per axis
+// with scale 2^B / (2 half) -- a power-of-two multiple of the 10-bit scale, so (p - lo) * scale is the
+// same fp32 value times 2^11 and the top 10 bits of the 21-bit coordinate are the 10-bit coordinate.
+template <class K> struct KeyTraits;
+template <> struct KeyTraits<unsigned int> {
+  static constexpr int kAxisBits = 10, kTop = 30;
+  static constexpr float kRefine = 1.0f;
+  static __device__ __forceinline__ unsigned int interleave(int x, int y, int z) {
+    return (expand_bits10((unsigned)x) << 2) | (expand_bits10((unsigned)y) << 1) | expand_bits10((unsigned)z);
+  }
+};
+template <> struct KeyTraits<unsigned long long> {
+  static constexpr int kAxisBits = 21, kTop = 63;
+  static constexpr float kRefine = 2048.0f;
+  static __device__ __forceinline__ unsigned long long interleave(int x, int y, int z) {
+    return (expand_bits21((unsigned long long)x) << 2) | (expand_bits21((unsigned long long)y) << 1) |
+           expand_bits21((unsigned long long)z);
+  }
+};
+
+template <class K>
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ posm, int n,
                                                         const TreeRoot* __restrict__ root,
-                                                        unsigned int* __restrict__ keys,
-                                                        int* __restrict__ idx) {
+                                                        K* __restrict__ keys, int* __restrict__ idx) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 p = posm[i];
-  const float s = root->scale;
+  const float s = root->scale * KeyTraits<K>::kRefine;
+  const int top = (1 << KeyTraits<K>::kAxisBits) - 1;
   int qx = (int)((p.x - root->lo[0]) * s);
   int qy = (int)((p.y - root->lo[1]) * s);
   int qz = (int)((p.z - root->lo[2]) * s);
-  qx = min(max(qx, 0), 1023); qy = min(max(qy, 0), 1023); qz = min(max(qz, 0), 1023);
-  keys[i] = (expand_bits10((unsigned)qx) << 2) | (expand_bits10((unsigned)qy) << 1) |
-            expand_bits10((unsigned)qz);
+  qx = min(max(qx, 0), top); qy = min(max(qy, 0), top); qz = min(max(qz, 0), top);
+  keys[i] = KeyTraits<K>::interleave(qx, qy, qz);
   idx[i] = i;
 }
 
@@ -138,8 +176,8 @@ struct TreeArrays {
 // ---------------------------------------------------------------------------------------
 
 // how many of the `cap` bodies on one side of body i (dir = -1 / +1) share its prefix (key >> sp)
-__device__ __forceinline__ int side_extent(const unsigned int* __restrict__ keys, int i, int dir,
-                                           int cap, unsigned int prefix, int sp) {
+template <class K>
+__device__ __forceinline__ int side_extent(const K* __restrict__ keys, int i, int dir, int cap, K prefix, int sp) {
   int lo = 0, hi = cap;  // the answer is in [lo, hi]; the predicate is monotone (sorted keys)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -148,70 +186,89 @@ __device__ __forceinline__ int side_extent(const unsigned int* __restrict__ keys
   return lo;
 }
 
-__global__ __launch_bounds__(kBlock) void tree_flags_kernel(const unsigned int* __restrict__ keys,
+template <class K>
+__global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict__ keys,
                                                             int n, int max_depth, int leaf_max,
-                                                            int* __restrict__ flag) {
+                                                            int* __restrict__ flag, unsigned int* __restrict__ lvlmask) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const unsigned int k = keys[i];
-  // first body of its group at level L  <=>  (d >> (30 - 3L)) != 0; body 0 heads every level
-  const unsigned int d = i == 0 ? 0xffffffffu : (k ^ keys[i - 1]);
+  const K k = keys[i];
+  // first body of its group at level L  <=>  (d >> (top - 3L)) != 0; body 0 heads every level
+  const K d = i == 0 ? ~(K)0 : (k ^ keys[i - 1]);
   bool open = true;  // the parent group is an internal node (level 0 has no parent)
+  unsigned int mask = 0;
   for (int L = 0; L <= max_depth; L++) {
-    const int shift = 30 - 3 * L;
+    const int shift = KeyTraits<K>::kTop - 3 * L;
     if (L > 0 && open) {
       const int sp = shift + 3;
-      const unsigned int prefix = k >> sp;
+      const K prefix = k >> sp;
       const int a = side_extent(keys, i, -1, min(i, leaf_max), prefix, sp);
       int b = 0;
       if (a < leaf_max) b = side_extent(keys, i, +1, min(n - 1 - i, leaf_max - a), prefix, sp);
       open = a + b >= leaf_max;  // parent holds at least a + b + 1 > leaf_max bodies
     }
-    flag[(size_t)L * n + i] = (open && (d >> shift) != 0u) ? 1 : 0;
+    const bool node = open && (d >> shift) != 0;
+    flag[(size_t)L * n + i] = node ? 1 : 0;
+    if (node) mask |= 1u << L;
   }
+  lvlmask[i] = mask;  // levels at which body i heads a node: the fill pass walks these bits only
 }
 
-__global__ __launch_bounds__(kBlock) void tree_fill_kernel(const unsigned int* __restrict__ keys,
+// One thread per BODY: it fills the nodes this body heads (the set bits of its level mask; 1.3 nodes per
+// body on average), instead of one thread per (level, body) entry of the flag array, 21 of 22 of which
+// would only find a zero flag (145 -> 60 us at N = 2^20, 21 levels).
+template <class K>
+__global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__ keys,
                                                            int n, int max_depth, int leaf_max,
-                                                           const int* __restrict__ flag,
+                                                           const unsigned int* __restrict__ lvlmask,
                                                            const int* __restrict__ incl,
                                                            TreeArrays t, int capacity,
                                                            int* __restrict__ level_base) {
-  const size_t total = (size_t)(max_depth + 1) * n;
-  const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= total) return;
-  const int L = (int)(e / n), i = (int)(e - (size_t)L * n);
-  if (i == 0) {  // ids of level L start where the scan of the levels above ended
-    level_base[L] = L == 0 ? 0 : min(incl[e - 1], capacity);
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i <= max_depth) {  // thread L of the first block (256 > levels): ids of level L start where the scan of
+    const int L = i;     // the levels above ended
+    const size_t total = (size_t)(max_depth + 1) * n;
+    level_base[L] = L == 0 ? 0 : min(incl[(size_t)L * n - 1], capacity);
     if (L == max_depth) level_base[L + 1] = min(incl[total - 1], capacity);
   }
-  if (!flag[e]) return;
-  const int nid = incl[e] - 1;
-  if (nid >= capacity) return;  // cannot happen with the capacity bound; never write past it
-  const int shift = 30 - 3 * L;
-  // one past the last body of the group: first j > i with another prefix
-  int last = n;
-  if (L > 0) {
-    const unsigned int prefix = keys[i] >> shift;
-    int lo = i + 1, hi = n;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((keys[mid] >> shift) == prefix) lo = mid + 1; else hi = mid;
+  if (i >= n) return;
+  unsigned int m = lvlmask[i];
+  const K key = keys[i];
+  while (m) {
+    const int L = __ffs(m) - 1;
+    m &= m - 1;
+    const size_t e = (size_t)L * n + i;
+    const int nid = incl[e] - 1;
+    if (nid >= capacity) continue;  // cannot happen with the capacity bound; never write past it
+    const int shift = KeyTraits<K>::kTop - 3 * L;
+    // one past the last body of the group: first j > i with another prefix
+    int last = n;
+    if (L > 0) {
+      const K prefix = key >> shift;
+      int lo = i + 1, hi = n;
+      // gallop first: groups are short (a node of a deep level holds a handful of bodies)
+      int step = 1;
+      while (lo + step < hi && (keys[lo + step - 1] >> shift) == prefix) { lo += step; step <<= 1; }
+      hi = min(hi, lo + step);
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((keys[mid] >> shift) == prefix) lo = mid + 1; else hi = mid;
+      }
+      last = lo;
     }
-    last = lo;
+    t.first[nid] = i;
+    t.last[nid] = last;
+    int c0 = -1, c1 = -1;
+    if (L < max_depth && last - i > leaf_max) {
+      // children: the flagged bodies of level L + 1 inside [i, last); body i is always one of them
+      const size_t ce = (size_t)(L + 1) * n;
+      c0 = incl[ce + i] - 1;
+      c1 = incl[ce + last - 1] - 1;
+      if (c1 >= capacity) { c0 = -1; c1 = -1; }
+    }
+    t.child0[nid] = c0;
+    t.child_last[nid] = c1;
   }
-  t.first[nid] = i;
-  t.last[nid] = last;
-  int c0 = -1, c1 = -1;
-  if (L < max_depth && last - i > leaf_max) {
-    // children: the flagged bodies of level L + 1 inside [i, last); body i is always one of them
-    const size_t ce = (size_t)(L + 1) * n;
-    c0 = incl[ce + i] - 1;
-    c1 = incl[ce + last - 1] - 1;
-    if (c1 >= capacity) { c0 = -1; c1 = -1; }
-  }
-  t.child0[nid] = c0;
-  t.child_last[nid] = c1;
 }
 
 // monopoles of one level (deepest first) + the packed traversal records
@@ -410,7 +467,9 @@ __device__ __forceinline__ float bh_dist2(float dx, float dy, float dz) {
 // at a fixed tree level left the replica owning a dense core with most of the work).  The
 // replicas' fp64 partial sums are added in replica order by bh_combine_kernel (deterministic).
 // ---------------------------------------------------------------------------------------
-template <bool GUARD, bool SPLIT>
+// HIST: diagnostics build of the same walk (lanes testing / accepting per node, nbody_hip_tree_count_visits);
+// kept out of the production instantiation: the two extra scalar tests per node cost 13 % of the walk.
+template <bool GUARD, bool SPLIT, bool HIST = false>
 __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
     const int* __restrict__ idx, int t_first, int n, float theta2, float eps2, float G,
@@ -504,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
       // inequality without the IEEE division sequence; the oracle uses the same form
       const bool far = nd.size2 < theta2 * dist2;
       const unsigned long long F = __ballot(far);
-      if (visit_count) {  // diagnostics (nbody_hip_tree_count_visits): lanes that test / accept this node
+      if constexpr (HIST) {  // lanes that test / accept this node
         if (lane == 0) {
           atomicAdd(&visit_count[1 + __popcll(M)], 1ull);
           atomicAdd(&visit_count[66 + __popcll(M & F)], 1ull);
@@ -583,16 +642,17 @@ static_assert(sizeof(RefOctreeNode) == 76, "OctreeNode layout");
 struct nbody_hip_tree {
   nbody_hip_ctx* ctx = nullptr;
   size_t max_particles = 0;
-  int max_depth = kMaxDepth;
+  int max_depth = kDefaultDepth;
   int leaf_max = 1;
   int capacity = 0;
   unsigned int* d_enc = nullptr;
   TreeRoot* d_root = nullptr;
-  int* d_level_base = nullptr;  // kMaxDepth + 2 ints
-  unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
+  int* d_level_base = nullptr;  // kMaxDepth + 3 ints
+  void *d_keys_a = nullptr, *d_keys_b = nullptr;  // 32-bit keys up to depth 10, 64-bit keys beyond
+  bool wide() const { return max_depth > kDepth32; }
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
-  int *d_flag = nullptr, *d_incl = nullptr;  // (kMaxDepth + 1) * max_particles each, level-major
+  int *d_flag = nullptr, *d_incl = nullptr;  // (max_depth + 1) * max_particles each, level-major
   TreeArrays t{};
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -619,16 +679,43 @@ static hipError_t dmalloc(T** p, size_t count) {
   return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
 }
 
+// everything whose size depends on the tree shape: keys (32- or 64-bit), the level-major flag / scan
+// arrays, the sort / scan scratch and the node arrays
 static int tree_alloc_nodes(nbody_hip_tree* g) {
-  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m};
+  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m,
+                  g->d_keys_a, g->d_keys_b, g->d_flag, g->d_incl, g->d_tmp};
   for (void* p : ptrs) (void)hipFree(p);
   g->t = TreeArrays{};
+  g->d_keys_a = g->d_keys_b = nullptr;
+  g->d_flag = g->d_incl = nullptr;
+  g->d_tmp = nullptr;
   const size_t n = g->max_particles;
   // leaves <= n; internal nodes per level <= n / (leaf_max + 1)
   size_t cap = n + (size_t)(g->max_depth + 1) * (n / (size_t)(g->leaf_max + 1) + 1) + 16;
   if (cap > 0x0fffffffu) cap = 0x0fffffffu;  // 28-bit child ids
   g->capacity = (int)cap;
-  hipError_t e = dmalloc(&g->t.first, cap);
+  const size_t kbytes = n * (g->wide() ? sizeof(unsigned long long) : sizeof(unsigned int));
+  const size_t nflag = (size_t)(g->max_depth + 1) * n;
+  hipError_t e = hipMalloc(&g->d_keys_a, kbytes);
+  if (e == hipSuccess) e = hipMalloc(&g->d_keys_b, kbytes);
+  if (e == hipSuccess) e = dmalloc(&g->d_flag, nflag);
+  if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
+  if (e == hipSuccess) {
+    size_t t1 = 0, t2 = 0;
+    if (g->wide())
+      e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, static_cast<unsigned long long*>(g->d_keys_a),
+                                                static_cast<unsigned long long*>(g->d_keys_b), g->d_idx_a, g->d_idx_b,
+                                                n, 0, 63, g->ctx->stream);
+    else
+      e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, static_cast<unsigned int*>(g->d_keys_a),
+                                                static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
+                                                30, g->ctx->stream);
+    if (e == hipSuccess)
+      e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, nflag, rocprim::plus<int>(), g->ctx->stream);
+    g->tmp_bytes = t1 > t2 ? t1 : t2;
+    if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
+  }
+  if (e == hipSuccess) e = dmalloc(&g->t.first, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.last, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.child0, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.child_last, cap);
@@ -637,7 +724,8 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   if (e == hipSuccess) e = dmalloc(&g->t.m, cap);
   if (e != hipSuccess)
     return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
-                    "Barnes-Hut node allocation (%zu nodes): %s", cap, hipGetErrorString(e));
+                    "Barnes-Hut tree allocation (%zu bodies, depth %d, %zu nodes): %s", n, g->max_depth, cap,
+                    hipGetErrorString(e));
   return NBODY_HIP_OK;
 }
 
@@ -654,26 +742,12 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   hipError_t e = dmalloc(&g->d_enc, 8);
   if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
-  if (e == hipSuccess) e = dmalloc(&g->d_keys_a, n);
-  if (e == hipSuccess) e = dmalloc(&g->d_keys_b, n);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_a, n);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_b, n);
   if (e == hipSuccess) e = dmalloc(&g->d_sorted, n);
-  const size_t nflag = (size_t)(kMaxDepth + 1) * n;
-  if (e == hipSuccess) e = dmalloc(&g->d_flag, nflag);
-  if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
   if (e == hipSuccess) e = dmalloc(&g->d_visits, kVisitWords);
   if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
   if (e == hipSuccess) e = dmalloc(&g->d_prefix, (size_t)kPrefixMax + 1);
-  if (e == hipSuccess) {
-    size_t t1 = 0, t2 = 0;
-    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n, 0,
-                                  30, ctx->stream);
-    if (e == hipSuccess)
-      e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, nflag, rocprim::plus<int>(), ctx->stream);
-    g->tmp_bytes = t1 > t2 ? t1 : t2;
-    if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
-  }
   if (e != hipSuccess) {
     tree_release(g);
     return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
@@ -702,6 +776,11 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_depth must be in [1, %d]", kMaxDepth);
   if (leaf_max < 1 || leaf_max > 1024)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "leaf_max must be in [1, 1024]");
+  // node ids are 28-bit: a deep tree over very many bodies does not fit the bound on its node count
+  if (max_depth > kDepth32 &&
+      (size_t)g->max_particles + (size_t)(max_depth + 1) * (g->max_particles / (size_t)(leaf_max + 1) + 1) + 16 > 0x0fffffffu)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_depth %d with leaf_max %d needs more than 2^28 nodes for %zu bodies",
+                    max_depth, leaf_max, g->max_particles);
   NBH_HIP(hipSetDevice(g->ctx->device));
   NBH_HIP(hipStreamSynchronize(g->ctx->stream));
   g->max_depth = max_depth;
@@ -725,26 +804,33 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
   }
   hipLaunchKernelGGL(tree_root_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->d_root, g->d_level_base);
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_root,
-                     g->d_keys_a, g->d_idx_a);
-  NBH_LAUNCH_CHECK();
-  size_t tmp = g->tmp_bytes;
-  NBH_HIP(rocprim::radix_sort_pairs<SortConfig>(g->d_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
-                                    0, 30, st));
-  hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
-  NBH_LAUNCH_CHECK();
-  // topology of every level: flags, one scan, fill (see tree_flags_kernel)
+  // topology of every level: keys, sort, flags, one scan, fill (see tree_flags_kernel)
   const int levels = g->max_depth + 1;
   const size_t total = (size_t)levels * n;
-  hipLaunchKernelGGL(tree_flags_kernel, dim3(blocks), dim3(kBlock), 0, st, g->d_keys_b, ni, g->max_depth,
-                     g->leaf_max, g->d_flag);
-  NBH_LAUNCH_CHECK();
-  tmp = g->tmp_bytes;
-  NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, g->d_flag, g->d_incl, total, rocprim::plus<int>(), st));
-  hipLaunchKernelGGL(tree_fill_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                     g->d_keys_b, ni, g->max_depth, g->leaf_max, g->d_flag, g->d_incl, g->t, g->capacity,
-                     g->d_level_base);
-  NBH_LAUNCH_CHECK();
+  auto topology = [&](auto* ka, auto* kb, int key_bits) -> int {
+    using K = std::remove_pointer_t<decltype(ka)>;
+    hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_root, ka, g->d_idx_a);
+    NBH_LAUNCH_CHECK();
+    size_t tmp = g->tmp_bytes;
+    NBH_HIP(rocprim::radix_sort_pairs<SortConfig>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, 0, key_bits, st));
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
+    hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                       g->d_flag, reinterpret_cast<unsigned int*>(g->d_idx_a));  // idx_a is free after the sort
+    NBH_LAUNCH_CHECK();
+    tmp = g->tmp_bytes;
+    NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, g->d_flag, g->d_incl, total, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(tree_fill_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                       reinterpret_cast<const unsigned int*>(g->d_idx_a), g->d_incl, g->t, g->capacity,
+                       g->d_level_base);
+    NBH_LAUNCH_CHECK();
+    return NBODY_HIP_OK;
+  };
+  if (g->wide()) {
+    if (int rc = topology(static_cast<unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b), 63))
+      return rc;
+  } else {
+    if (int rc = topology(static_cast<unsigned int*>(g->d_keys_a), static_cast<unsigned int*>(g->d_keys_b), 30)) return rc;
+  }
   if (ni <= kPrefixMax) {
     // small tree: every node's monopole from the prefix sums of the sorted bodies (see above)
     hipLaunchKernelGGL(prefix_bodies_kernel, dim3(1), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix);
@@ -825,7 +911,14 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
                      g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,                     \
                      unit_max, g->d_partial)
-  if (K == 1) {
+  if (K == 1 && visits) {  // counting on: the diagnostics instantiation (plain walk only)
+    if (guard) hipLaunchKernelGGL((bh_traverse_kernel<true, false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                                  g->t.rec, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,
+                                  unit_max, g->d_partial);
+    else hipLaunchKernelGGL((bh_traverse_kernel<false, false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                            g->t.rec, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,
+                            unit_max, g->d_partial);
+  } else if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
   } else {
     if (guard) NBH_BH_LAUNCH(true, true, dim3(blocks, K)); else NBH_BH_LAUNCH(false, true, dim3(blocks, K));
@@ -932,11 +1025,18 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
   if (capacity_nodes < count)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "node buffer too small: %d < %d", capacity_nodes, count);
   std::vector<NodeRec> rec(count);
-  std::vector<unsigned int> keys(n);
+  std::vector<unsigned long long> keys(n);  // 30-bit keys widened: one code path below
   std::vector<int> idx(n);
   TreeRoot root;
   NBH_HIP(hipMemcpy(rec.data(), g->t.rec, (size_t)count * sizeof(NodeRec), hipMemcpyDeviceToHost));
-  NBH_HIP(hipMemcpy(keys.data(), g->d_keys_b, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  const int axis_bits = g->wide() ? 21 : 10;
+  if (g->wide()) {
+    NBH_HIP(hipMemcpy(keys.data(), g->d_keys_b, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  } else {
+    std::vector<unsigned int> k32(n);
+    NBH_HIP(hipMemcpy(k32.data(), g->d_keys_b, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) keys[i] = k32[i];
+  }
   NBH_HIP(hipMemcpy(idx.data(), g->d_idx_b, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   NBH_HIP(hipMemcpy(&root, g->d_root, sizeof(root), hipMemcpyDeviceToHost));
   RefOctreeNode* out = static_cast<RefOctreeNode*>(host_nodes);
@@ -946,16 +1046,16 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
     RefOctreeNode& o = out[nid];
     const int first = rec[nid].first, cnt = rec[nid].count;
     const unsigned int ci = rec[nid].child;
-    const unsigned int k = keys[first];
+    const unsigned long long k = keys[first];
     unsigned int q[3] = {0, 0, 0};
-    for (int bit = 0; bit < 10; bit++) {
-      q[0] |= ((k >> (3 * bit + 2)) & 1u) << bit;
-      q[1] |= ((k >> (3 * bit + 1)) & 1u) << bit;
-      q[2] |= ((k >> (3 * bit + 0)) & 1u) << bit;
+    for (int bit = 0; bit < axis_bits; bit++) {
+      q[0] |= (unsigned)((k >> (3 * bit + 2)) & 1ull) << bit;
+      q[1] |= (unsigned)((k >> (3 * bit + 1)) & 1ull) << bit;
+      q[2] |= (unsigned)((k >> (3 * bit + 0)) & 1ull) << bit;
     }
     const float h = ldexpf(root.half, -level);
     for (int ax = 0; ax < 3; ax++)
-      o.center[ax] = root.lo[ax] + ((float)(q[ax] >> (10 - level)) + 0.5f) * (2.0f * h);
+      o.center[ax] = root.lo[ax] + ((float)(q[ax] >> (axis_bits - level)) + 0.5f) * (2.0f * h);
     o.half_size = h;
     o.com[0] = rec[nid].cx; o.com[1] = rec[nid].cy; o.com[2] = rec[nid].cz;
     o.total_mass = rec[nid].mass;
@@ -965,8 +1065,8 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
     o.particle_count = cnt;
     if (!o.is_leaf) {
       const int c0 = (int)(ci & 0x0fffffffu), nc = (int)(ci >> 28);
-      const int shift = 27 - 3 * level;
-      for (int c = c0; c < c0 + nc; c++) o.children[(keys[rec[c].first] >> shift) & 7u] = c;
+      const int shift = 3 * axis_bits - 3 - 3 * level;
+      for (int c = c0; c < c0 + nc; c++) o.children[(keys[rec[c].first] >> shift) & 7ull] = c;
     }
   }
   return NBODY_HIP_OK;

@@ -472,9 +472,11 @@ ORACLE_API void oracle_direct_cutoff_forces(size_t n, const float* x, const floa
 /*     its CONTRACT is followed:                                                */
 /*       root cube   centre = bbox midpoint, half = max extent/2 + 0.001 (:339-344) */
 /*       octree      every cell with more than `leaf_max` bodies is split, down  */
-/*                   to `max_depth` levels (cells are addressed on the           */
-/*                   2^max_depth integer grid of the root cube, the Morton       */
-/*                   quantisation of :23-38 applied to the cube)                 */
+/*                   to `max_depth` levels (cells are addressed on the 2^B       */
+/*                   integer grid of the root cube, the Morton quantisation of   */
+/*                   :23-38 applied to the cube; B = 10 bits per axis up to      */
+/*                   depth 10, 21 bits per axis up to depth 21 -- the reference   */
+/*                   caps its insertion at depth 20, :363)                       */
 /*       monopoles   mass and centre of mass per node                            */
 /*       traversal   :164-195 -- skip massless nodes; accept a node if it is a   */
 /*                   leaf or (2 half)^2 / (d^2 + eps^2) < theta^2; a leaf's       */
@@ -493,7 +495,8 @@ typedef struct {
 typedef struct {
   ONode* nodes;
   int count, cap;
-  const uint32_t* key;  /* sorted keys */
+  const uint64_t* key;  /* sorted keys, 3 axis_bits wide */
+  int axis_bits;        /* 10 or 21 */
   const int* order;     /* sorted position -> body index */
   const float *x, *y, *z, *m;
   float lo[3], half;
@@ -534,6 +537,21 @@ ORACLE_API uint32_t oracle_bh_key(float px, float py, float pz, const float lo[3
          expand_bits10((uint32_t)q[2]);
 }
 
+/* the same with `bits` (10 or 21) per axis; `scale` = 2^bits / (2 half).  Plain bit loop: the oracle
+ * does not have to be fast here. */
+static uint64_t bh_key_bits(float px, float py, float pz, const float lo[3], float scale, int bits) {
+  const float p[3] = {px, py, pz};
+  const int top = (1 << bits) - 1;
+  uint64_t key = 0;
+  for (int a = 0; a < 3; a++) {
+    float f = (p[a] - lo[a]) * scale;
+    int v = (int)f;
+    uint64_t q = (uint64_t)(v < 0 ? 0 : (v > top ? top : v));
+    for (int b = 0; b < bits; b++) key |= ((q >> b) & 1ull) << (3 * b + (2 - a));
+  }
+  return key;
+}
+
 static int otree_new(OTree* t) {
   if (t->count == t->cap) {
     t->cap = t->cap ? t->cap * 2 : 1024;
@@ -553,14 +571,14 @@ static int otree_build(OTree* t, int first, int count, int level) {
     nd->first = first;
     nd->count = count;
     /* geometry from the key prefix */
-    uint32_t k = t->key[first];
+    uint64_t k = t->key[first];
     uint32_t ix = 0, iy = 0, iz = 0;
-    for (int b = 0; b < 10; b++) {
-      ix |= ((k >> (3 * b + 2)) & 1u) << b;
-      iy |= ((k >> (3 * b + 1)) & 1u) << b;
-      iz |= ((k >> (3 * b + 0)) & 1u) << b;
+    for (int b = 0; b < t->axis_bits; b++) {
+      ix |= (uint32_t)((k >> (3 * b + 2)) & 1ull) << b;
+      iy |= (uint32_t)((k >> (3 * b + 1)) & 1ull) << b;
+      iz |= (uint32_t)((k >> (3 * b + 0)) & 1ull) << b;
     }
-    int sh = 10 - level;
+    int sh = t->axis_bits - level;
     float h = ldexpf(t->half, -level);
     nd->half = h;
     nd->cx = t->lo[0] + ((float)(ix >> sh) + 0.5f) * (2.0f * h);
@@ -588,13 +606,13 @@ static int otree_build(OTree* t, int first, int count, int level) {
     }
     return ni;
   }
-  int shift = 27 - 3 * level;
+  int shift = 3 * t->axis_bits - 3 - 3 * level;
   int k = first;
   double mx = 0, my = 0, mz = 0, ms = 0;
   while (k < first + count) {
-    uint32_t oct = (t->key[k] >> shift) & 7u;
+    uint64_t oct = (t->key[k] >> shift) & 7ull;
     int e = k;
-    while (e < first + count && ((t->key[e] >> shift) & 7u) == oct) e++;
+    while (e < first + count && ((t->key[e] >> shift) & 7ull) == oct) e++;
     int c = otree_build(t, k, e - k, level + 1);
     t->nodes[ni].child[oct] = c;
     ONode* cn = &t->nodes[c];
@@ -608,7 +626,7 @@ static int otree_build(OTree* t, int first, int count, int level) {
   return ni;
 }
 
-typedef struct { uint32_t key; int idx; } KeyIdx;
+typedef struct { uint64_t key; int idx; } KeyIdx;
 /* |d|^2 of the Barnes-Hut walk as the device code forms it: dx*dx, then two fused multiply-adds
  * (force_barnes_hut.cu:165 `dx*dx + dy*dy + dz*dz` -- nvcc contracts exactly this chain with its
  * default -fmad=true; the HIP walk writes the same chain explicitly, so the opening decisions of
@@ -629,27 +647,31 @@ ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y
                                         float theta, int max_depth, int leaf_max,
                                         double* root_mass, int* node_count, int* order_out) {
   if (max_depth < 1) max_depth = 1;
-  if (max_depth > 10) max_depth = 10;
+  if (max_depth > 21) max_depth = 21;
   if (leaf_max < 1) leaf_max = 1;
+  /* 10 bits per axis up to depth 10 (the 30-bit keys of :23-38), 21 beyond; the finer grid refines the
+   * coarser one: its scale is the 10-bit scale times 2^11, an exact fp32 scaling */
+  const int axis_bits = max_depth <= 10 ? 10 : 21;
   float center[3], half;
   oracle_bh_root(n, x, y, z, center, &half);
   OTree t;
   memset(&t, 0, sizeof(t));
   t.half = half;
   for (int a = 0; a < 3; a++) t.lo[a] = center[a] - half;
-  const float scale = 1024.0f / (2.0f * half);
+  const float scale = (1024.0f / (2.0f * half)) * (axis_bits == 10 ? 1.0f : 2048.0f);
   KeyIdx* ki = (KeyIdx*)malloc(n * sizeof(KeyIdx));
   for (size_t i = 0; i < n; i++) {
-    ki[i].key = oracle_bh_key(x[i], y[i], z[i], t.lo, scale);
+    ki[i].key = axis_bits == 10 ? (uint64_t)oracle_bh_key(x[i], y[i], z[i], t.lo, scale)
+                                : bh_key_bits(x[i], y[i], z[i], t.lo, scale, axis_bits);
     ki[i].idx = (int)i;
   }
   qsort(ki, n, sizeof(KeyIdx), cmp_keyidx);
-  uint32_t* key = (uint32_t*)malloc(n * sizeof(uint32_t));
+  uint64_t* key = (uint64_t*)malloc(n * sizeof(uint64_t));
   int* order = (int*)malloc(n * sizeof(int));
   int* pos_of = (int*)malloc(n * sizeof(int));
   for (size_t k = 0; k < n; k++) { key[k] = ki[k].key; order[k] = ki[k].idx; pos_of[ki[k].idx] = (int)k; }
   free(ki);
-  t.key = key; t.order = order; t.x = x; t.y = y; t.z = z; t.m = m;
+  t.key = key; t.axis_bits = axis_bits; t.order = order; t.x = x; t.y = y; t.z = z; t.m = m;
   t.max_depth = max_depth; t.leaf_max = leaf_max;
   otree_build(&t, 0, (int)n, 0);
   if (root_mass) *root_mass = t.nodes[0].mass;
@@ -662,7 +684,7 @@ ORACLE_API int oracle_barnes_hut_forces(size_t n, const float* x, const float* y
     int i = (int)tidx[k];
     float xi = x[i], yi = y[i], zi = z[i];
     double a0 = 0, a1 = 0, a2 = 0;
-    int stack[8 * 12];
+    int stack[8 * 24];
     int sp = 0;
     stack[sp++] = 0;
     while (sp > 0) {

@@ -150,7 +150,7 @@ class Oracle:
         self.L.oracle_direct_cutoff_forces(x.size, x, y, z, m, idx.size, idx, ax, ay, az, G, eps2, cutoff)
         return ax, ay, az
 
-    def barnes_hut_forces(self, x, y, z, m, idx, G, eps2, theta, max_depth=10, leaf_max=1,
+    def barnes_hut_forces(self, x, y, z, m, idx, G, eps2, theta, max_depth=20, leaf_max=1,
                           want_order=False):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         ax, ay, az = (np.empty(idx.size, np.float32) for _ in range(3))

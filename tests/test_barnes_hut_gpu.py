@@ -374,3 +374,98 @@ def test_config4_energy_drift_10k_steps(nb, ctx, which, eps, tol_e, tol_pe):
           f"max |dE|/|E0| = {worst / abs(e0):.3e}, max |dE|/|PE0| = {worst / abs(pe0):.3e}")
     assert worst / abs(e0) < tol_e, f"max |dE|/|E0| = {worst / abs(e0):.3e}"
     assert worst / abs(pe0) < tol_pe, f"max |dE|/|PE0| = {worst / abs(pe0):.3e}"
+
+
+# Trees deeper than the 30-bit keys of the reference's Morton code (ref: force_barnes_hut.cu:23-38; its
+# host insertion goes down to depth 20, :363): max_depth 11..21 switches to 63-bit keys (21 bits per axis).
+# Body by body against the oracle's tree of the same shape, on a cluster whose core is far denser than
+# a depth-10 cell, with coincident bodies (which stay together in a deepest leaf at any depth).
+@pytest.mark.parametrize("max_depth,leaf_max", [(11, 1), (14, 1), (21, 1), (16, 4), (10, 1)])
+def test_deep_tree_matches_oracle(nb, oracle, ctx, max_depth, leaf_max):
+    n = 6000
+    ic = nb.ic.plummer(n, seed=13, a=0.002, rmax=40.0)      # scale length 0.002 ...
+    for c in range(8):                                        # ... inside a box of +-8 (eight far bodies): the whole
+        for b, k in enumerate(("pos_x", "pos_y", "pos_z")):   # core sits in a handful of depth-10 cells
+            ic[k][c] = 8.0 if (c >> b) & 1 else -8.0
+    for k in ("pos_x", "pos_y", "pos_z"):
+        ic[k][100:140] = ic[k][100]                           # 40 coincident bodies
+    d, _ = to_device(nb, ic)
+    tree = nb.BarnesHutTree(n)
+    tree.setParams(max_depth, leaf_max)
+    tree.build(d)
+    eps, theta, G = 1e-4, 0.6, 1.0
+    tree.computeForces(d, theta, G, eps)
+    a = acc_of(d)
+    r = oracle.barnes_hut_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], np.arange(n), G,
+                                 float(np.float32(eps) ** 2), theta, max_depth, leaf_max)
+    assert tree.getNodeCount() == r[4]
+    assert abs(tree.stats()["root_mass"] - r[3]) < 1e-6 * r[3]
+    ref = np.stack(r[:3], 1)
+    nz = np.linalg.norm(ref, axis=1) > 0
+    assert rel_err(a[nz], ref[nz]).max() < TOL
+    nodes = tree.copyNodesToHost()
+    deepest = nodes["particle_count"][nodes["is_leaf"]].max()
+    half = nodes["half_size"]
+    assert np.isclose(half.min(), half[0] * 2.0 ** -min(max_depth, int(np.round(np.log2(half[0] / half.min())))))
+    if max_depth == 21 and leaf_max == 1:
+        assert deepest == 40          # only the coincident bodies still share a leaf
+    if max_depth == 10:
+        assert deepest > 100          # 30-bit keys cannot resolve the core
+    # the geometry of every node contains its bodies' centre of mass
+    inside = np.all(np.abs(nodes["center_of_mass"] - nodes["center"]) <= half[:, None] * 1.0001 + 1e-6, axis=1)
+    assert inside[nodes["total_mass"] > 0].all()
+
+
+def test_deep_tree_parameter_errors(nb, ctx):
+    tree = nb.BarnesHutTree(1000)
+    with pytest.raises(nb.ValidationException):
+        tree.setParams(22, 1)
+    with pytest.raises(nb.ValidationException):
+        tree.setParams(0, 1)
+    big = nb.BarnesHutTree(60_000_000)
+    with pytest.raises(nb.ValidationException, match="2\\^28 nodes"):
+        big.setParams(21, 1)          # 12 n nodes would not fit the 28-bit node ids
+    big.setParams(21, 64)             # with wider leaves it does
+
+
+# N = 2^21 Plummer sphere: the core holds dozens of bodies per depth-10 cell; at depth 16 every leaf holds
+# one body again (up to exact coincidences).  Sampled bodies against the oracle's depth-16 tree.
+def test_deep_tree_large_plummer(nb, oracle, ctx):
+    import time
+    n = 1 << 21
+    ic = nb.ic.plummer(n, seed=42, a=0.1, rmax=100.0)    # a 10x more compact core than the bench's sphere
+    d, _ = to_device(nb, ic)
+    out = {}
+    for depth in (10, 16):
+        tree = nb.BarnesHutTree(n)
+        tree.setParams(depth, 1)
+        tree.build(d)
+        tree.computeForces(d, 0.5, 1.0, 1e-3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tree.build(d)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tree.computeForces(d, 0.5, 1.0, 1e-3)
+        torch.cuda.synchronize()
+        tw = (time.perf_counter() - t0) / 3
+        nodes = tree.copyNodesToHost()
+        leaf = nodes["is_leaf"]
+        out[depth] = dict(acc=acc_of(d), nodes=int(tree.getNodeCount()), max_leaf=int(nodes["particle_count"][leaf].max()),
+                          build_ms=tb * 1e3, walk_ms=tw * 1e3)
+        print(f"N = {n}, max_depth {depth}: {out[depth]['nodes']} nodes, largest leaf {out[depth]['max_leaf']} bodies, "
+              f"build {tb * 1e3:.2f} ms, walk {tw * 1e3:.2f} ms")
+        del tree, nodes
+    assert out[10]["max_leaf"] > 100 and out[16]["max_leaf"] * 50 < out[10]["max_leaf"]
+    idx = np.concatenate([np.linspace(0, n - 1, 96).astype(np.int64),
+                          np.argsort(ic["pos_x"] ** 2 + ic["pos_y"] ** 2 + ic["pos_z"] ** 2)[:96]])
+    r = oracle.barnes_hut_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx, 1.0,
+                                 float(np.float32(1e-3) ** 2), 0.5, 16, 1)
+    assert out[16]["nodes"] == r[4]
+    assert rel_err(out[16]["acc"][idx], np.stack(r[:3], 1)).max() < TOL
+    # both trees approximate the same sum: they agree to the theta = 0.5 accuracy
+    e = rel_err(out[16]["acc"][idx], out[10]["acc"][idx])
+    assert np.median(e) < 0.01
