@@ -56,6 +56,7 @@ __device__ __forceinline__ float wave_rot1(float v) {
 constexpr int kSymBlocksPerCU = 16;  // workgroups aimed at per CU (tools/sweep_mid.py)
 constexpr int kSymMinChunks = 4;     // at least 4 chunks (256 J bodies) per workgroup
 constexpr size_t kDetBudgetBytes = (size_t)24 << 30;  // slot planes of the deterministic mode: at most 24 GiB
+                                                      // (= 3.2e9 doubles: element offsets fit 32 bits)
 constexpr float kFar = 1.0e18f;  // padding bodies sit here: (3e36)^-3/2 underflows to 0, no mass test needed
 
 // DET (all-pairs form only): deterministic sums.  Instead of fp64 atomics every contribution gets a slot
@@ -147,13 +148,15 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
     const int pd = (q0 + q) / CPB, pc = (q0 + q) % CPB;
     if constexpr (DET) {
       if (pd > 0) {  // slot pd - 1 of the partner's bodies; a partner the half ring skips contributes zero
-        const int j = ((A + pd) % NB) * S + pc * 64 + lane;
+        // (wave-uniform slot base; 32-bit element offsets: the slot planes stay below 2^32 doubles)
+        double* slot = acc64 + (size_t)(pd - 1) * 3 * plane_i;
+        const unsigned int j = (unsigned int)(((A + pd) % NB) * S + pc * 64 + lane), pl = (unsigned int)plane_i;
         const int sb = q & 1;
-        const bool ok = partner_valid(pd);
+        const float keep = partner_valid(pd) ? m0 : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const float v = (slab[sb][0][c][lane] + slab[sb][1][c][lane]) + (slab[sb][2][c][lane] + slab[sb][3][c][lane]);
-          acc64[((size_t)(pd - 1) * 3 + c) * plane_i + (size_t)j] = ok ? (double)v * (double)m0 : 0.0;
+          slot[c * pl + j] = (double)v * (double)keep;
         }
       }
     } else if ((RECT || pd > 0) && partner_valid(pd)) {
@@ -253,9 +256,10 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
     const double fz = LACC ? lacc[(2 * R + r) * kBlock + tid] : sz[LACC ? 0 : r];
     if constexpr (DET) {
       double* slot = acc64 + (size_t)(D + blockIdx.y) * 3 * plane_i;
-      slot[(size_t)i] = fx * (double)m0;
-      slot[plane_i + (size_t)i] = fy * (double)m0;
-      slot[2 * plane_i + (size_t)i] = fz * (double)m0;
+      const unsigned int iu = (unsigned int)i, pl = (unsigned int)plane_i;
+      slot[iu] = fx * (double)m0;
+      slot[pl + iu] = fy * (double)m0;
+      slot[2u * pl + iu] = fz * (double)m0;
     } else {
       unsafeAtomicAdd(&acc64[(size_t)i], fx * (double)m0);
       unsafeAtomicAdd(&acc64[plane_i + (size_t)i], fy * (double)m0);
@@ -294,12 +298,18 @@ __global__ __launch_bounds__(kBlock) void mass_range_kernel(const float4* __rest
 
 // acc = G * acc64 ; SoA or float4 output ; optional fused Velocity-Verlet kick
 __global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
-    const double* __restrict__ acc64, size_t plane, int nslots, int n, float G, float4* __restrict__ acc4, int accumulate,
+    const double* __restrict__ acc64, size_t plane, int nslots, size_t plane_gen, int nslots_gen,
+    const unsigned int* __restrict__ mass_range, int n, float G, float4* __restrict__ acc4, int accumulate,
     float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, float* __restrict__ vx,
     float* __restrict__ vy, float* __restrict__ vz, const float* __restrict__ aox,
     const float* __restrict__ aoy, const float* __restrict__ aoz, float half_dt) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  if (mass_range) {  // the general-mass instantiation ran with a layout of its own (other bodies per lane)
+    const bool uniform = mass_range[0] == mass_range[1] && mass_range[2] == mass_range[3] &&
+                         mass_range[0] == mass_range[2] && ordered_to_float(mass_range[0]) > 0.f;
+    if (!uniform) { plane = plane_gen; nslots = nslots_gen; }
+  }
   double sx = 0.0, sy = 0.0, sz = 0.0;
   for (int k = 0; k < nslots; k++) {  // one slot with atomics; the deterministic mode's slots in a fixed order
     const double* p = acc64 + (size_t)k * 3 * plane;
@@ -331,17 +341,8 @@ static void launch_mass_range(nbody_hip_ctx* ctx, const float4* pi, int ni, cons
 template <int R, bool RECT>
 static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, const float4* pj, int nj,
                        int NB, int NBJ, int per, double* acci, double* accj, const unsigned int* enc,
-                       float eps2, bool det = false) {
+                       float eps2) {
   const size_t S = (size_t)kBlock * R;
-  if constexpr (!RECT) {
-    if (det) {
-      hipLaunchKernelGGL((direct_sym_kernel<R, false, true, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
-                         NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
-      hipLaunchKernelGGL((direct_sym_kernel<R, false, false, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
-                         NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
-      return;
-    }
-  }
   // both instantiations are queued; the one whose mass assumption does not hold exits at once
   hipLaunchKernelGGL((direct_sym_kernel<R, RECT, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
                      NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
@@ -366,49 +367,86 @@ static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
   return n >= 786432 ? 16 : (n >= 28000 ? 8 : 4);
 }
 
-int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
-                     float4* acc4, int accumulate, float* ax, float* ay, float* az, float* vx,
-                     float* vy, float* vz, const float* aox, const float* aoy, const float* aoz,
-                     float half_dt) {
-  const int R = sym_R(ctx, n, false);
+namespace {
+struct SymShape {  // launch shape of the all-pairs kernel for a given number of bodies per lane
+  int R, NB, D, per, splits;
+  size_t plane;
+};
+SymShape sym_shape(const nbody_hip_ctx* ctx, size_t n, int R) {
+  SymShape c;
+  c.R = R;
   const int S = kBlock * R;
-  const int NB = (int)((n + S - 1) / S);
-  const int D = NB / 2;
+  c.NB = (int)((n + S - 1) / S);
+  c.D = c.NB / 2;
   // workgroups = NB x splits; a split is a run of 64-body chunks of the flat (offset, chunk) list
-  const int total = (D + 1) * (S / 64);
-  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * kSymBlocksPerCU + NB - 1) / NB;
+  const int total = (c.D + 1) * (S / 64);
+  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * kSymBlocksPerCU + c.NB - 1) / c.NB;
   if (splits < 1) splits = 1;
   int per = (total + splits - 1) / splits;
   if (per < kSymMinChunks) per = kSymMinChunks;
   if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);  // whole partners when there are enough
-  splits = (total + per - 1) / per;
-  const size_t plane = (size_t)NB * S;
+  c.per = per;
+  c.splits = (total + per - 1) / per;
+  c.plane = (size_t)c.NB * S;
+  return c;
+}
+template <int R, bool EQM, bool DET>
+void launch_all_pairs(nbody_hip_ctx* ctx, const SymShape& c, const float4* posm, int n, double* acc64,
+                      const unsigned int* enc, float eps2) {
+  hipLaunchKernelGGL((direct_sym_kernel<R, false, EQM, DET>), dim3(c.NB, c.splits), dim3(kBlock), 0, ctx->stream, posm, n,
+                     posm, n, c.NB, c.NB, c.per, acc64, acc64, c.plane, c.plane, enc, eps2);
+}
+template <bool EQM, bool DET>
+void launch_all_pairs_R(nbody_hip_ctx* ctx, const SymShape& c, const float4* posm, int n, double* acc64,
+                        const unsigned int* enc, float eps2) {
+  switch (c.R) {
+    case 2: launch_all_pairs<2, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+    case 6: launch_all_pairs<6, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+    case 8: launch_all_pairs<8, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+    case 16: launch_all_pairs<16, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+    default: launch_all_pairs<4, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+  }
+}
+}  // namespace
+
+int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, float eps2,
+                     float4* acc4, int accumulate, float* ax, float* ay, float* az, float* vx,
+                     float* vy, float* vz, const float* aox, const float* aoy, const float* aoz,
+                     float half_dt) {
+  // Both instantiations (equal masses / general masses) are queued; the one whose assumption about the
+  // masses fails exits at once (decided on the device).  Each has a launch shape of its own:
+  const SymShape eq = sym_shape(ctx, n, sym_R(ctx, n, false));
   // deterministic mode: one slot per contribution (D reaction slots + one I-side slot per split); every
   // slot is written exactly once by the kernel, so nothing has to be cleared.  It needs 24 (D + splits)
   // bytes per body: taken when asked for (nbody_hip_direct_deterministic) and it fits the budget
-  const int nslots_det = D + splits;
-  const bool det = ctx->deterministic && (size_t)nslots_det * plane * 3 * sizeof(double) <= kDetBudgetBytes;
-  const int nslots = det ? nslots_det : 1;
-  const size_t acc_bytes = (size_t)nslots * plane * 3 * sizeof(double);  // three component planes per slot
+  const bool det = ctx->deterministic &&
+                   (size_t)(eq.D + eq.splits) * eq.plane * 3 * sizeof(double) <= kDetBudgetBytes;
+  // general masses at 16 bodies per lane: the slot stores push the kernel from 277 to 285 registers (191 ms
+  // against 170 ms with atomics at N = 2^20); 8 bodies per lane run it in 177 ms (tools/direct_det_probe.py)
+  const SymShape gen = (det && eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, 8) : eq;
+  const int nslots_eq = det ? eq.D + eq.splits : 1, nslots_gen = det ? gen.D + gen.splits : 1;
+  const size_t bytes_eq = (size_t)nslots_eq * eq.plane * 3 * sizeof(double);
+  const size_t bytes_gen = (size_t)nslots_gen * gen.plane * 3 * sizeof(double);
+  const size_t acc_bytes = bytes_eq > bytes_gen ? bytes_eq : bytes_gen;  // three component planes per slot
   if (int rc = ctx->partial.reserve(acc_bytes)) return rc;
   double* acc64 = static_cast<double*>(ctx->partial.ptr);
   if (!det) NBH_HIP(hipMemsetAsync(acc64, 0, acc_bytes, ctx->stream));
   if (int rc = ctx->reduce.reserve(64)) return rc;
   unsigned int* enc = static_cast<unsigned int*>(ctx->reduce.ptr);
-  const dim3 grid(NB, splits);
   const int ni = (int)n;
   launch_mass_range(ctx, posm, ni, posm, ni, enc);
-  switch (R) {
-    case 2: launch_sym<2, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
-    case 6: launch_sym<6, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
-    case 8: launch_sym<8, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
-    case 16: launch_sym<16, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
-    default: launch_sym<4, false>(ctx, grid, posm, ni, posm, ni, NB, NB, per, acc64, acc64, enc, eps2, det); break;
+  if (det) {
+    launch_all_pairs_R<true, true>(ctx, eq, posm, ni, acc64, enc, eps2);
+    launch_all_pairs_R<false, true>(ctx, gen, posm, ni, acc64, enc, eps2);
+  } else {
+    launch_all_pairs_R<true, false>(ctx, eq, posm, ni, acc64, enc, eps2);
+    launch_all_pairs_R<false, false>(ctx, gen, posm, ni, acc64, enc, eps2);
   }
   NBH_LAUNCH_CHECK();
   const int fblocks = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, acc64,
-                     plane, nslots, ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
+  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, acc64, eq.plane,
+                     nslots_eq, gen.plane, nslots_gen, enc, ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy,
+                     aoz, half_dt);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
@@ -446,10 +484,10 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
   }
   NBH_LAUNCH_CHECK();
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((ni + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, acci, plane_i, 1, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
+                     ctx->stream, acci, plane_i, 1, plane_i, 1, nullptr, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((nj + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, accj, plane_j, 1, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
+                     ctx->stream, accj, plane_j, 1, plane_j, 1, nullptr, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
