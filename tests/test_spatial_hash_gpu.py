@@ -108,6 +108,18 @@ def test_forces_match_oracle(nb, oracle, ctx, n, box, cell, cutoff, eps, tol):
     # determinism: a second evaluation is bitwise identical (stable binning)
     calc.computeForces(d)
     assert np.array_equal(acc_of(d), a)
+    # every force kernel of the grid against the oracle (1 = cell runs with binary-searched ranges,
+    # 2 / 3 / 4 = one wave per cell with 1 / 2 / 4 bodies per lane; the dense case has windows longer than
+    # a wave's LDS batch and cells with more bodies than one chunk of target slots)
+    g = calc.getGrid()
+    for kern in (1, 2, 3, 4):
+        g.tuning(kern)
+        calc.computeForces(d)
+        ak = acc_of(d)
+        assert np.all(ak[~nz] == 0), kern
+        if nz.any():
+            assert rel_err(ak[nz], ref[nz]).max() < tol, kern
+    g.tuning(0)
 
 
 # clustered input (Plummer): very uneven cell occupancy
