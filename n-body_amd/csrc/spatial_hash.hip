@@ -932,7 +932,11 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   int kern = g->tune_kernel;
   // measured (tools/hash_kernels.py, profiles/r02_hash_kernels.txt): rho 0.9: cell-run 0.16 ms vs 0.28;
   // rho 3.7: 0.74 vs 0.31 (R = 1) / 0.49 (R = 2); rho 14.6: 1.87 vs 1.20 / 1.02; rho 107: 6.7 vs 8.1 / 6.1
-  if (kern == 0) kern = !g->lb_valid || rho < 2.0 ? 1 : (rho < 8.0 ? 2 : 3);
+  // clustered bodies (tools/hash_kernels_sphere.py; rho = bodies per cell of the WHOLE grid, the occupied part
+  // is denser): sphere of 10,000 in a 21^3 grid, rho 1.1, cutoff 2 > cell: 0.050 vs 0.018 ms; 100,000 bodies,
+  // rho 10.8, cutoff 2: 0.86 vs 0.10 ms (the cell-run kernel's |cx_j - cx_i| test); rho 1.5 / 1.9: 0.079 /
+  // 0.78 vs 0.069 / 0.47 ms.  Uniform box at rho 0.9: 0.16 (cell runs) vs 0.28 ms.
+  if (kern == 0) kern = !g->lb_valid || rho < (strict ? 0.5 : 1.0) ? 1 : (rho < 8.0 ? 2 : 3);
   if (kern != 1 && g->lb_valid) {
     const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
     return launch_cell_forces(ctx, view, view, gx, gy, gz, g->lb_base, g->lb_base + g->lb_count, kern, guard, cutoff2,
