@@ -211,11 +211,17 @@ def test_full_size_properties(nb, oracle, ctx):
     eps2 = float(np.float32(1e-3) * np.float32(1e-3))
     a = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
     b = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
-    # the all-pairs case runs the symmetric kernel (direct_sym.hip), whose fp64 atomics commute
-    # only up to the last bit of the fp64 sum: the fp32 results agree to <= 1 ulp, almost always
-    # bit for bit; the one-sided kernel (below) is bitwise reproducible
-    diff = (a - b).abs()
-    assert int((diff > 0).sum()) < 100
+    # the all-pairs case runs the symmetric kernel (direct_sym.hip) with its deterministic slot sums
+    # (default): bit for bit, launch after launch; with fp64 atomics instead the fp32 results agree to
+    # <= 1 ulp, almost always bit for bit
+    assert torch.equal(a, b)
+    try:
+        ctx.deterministic(False)
+        c = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+    finally:
+        ctx.deterministic(True)
+    diff = (a - c).abs()
+    assert int((diff > 0).sum()) < 1000
     assert float((diff / a.abs().clamp_min(1e-30)).max()) < 2.5e-7
     try:
         ctx.tuning(1, 4, 0)
