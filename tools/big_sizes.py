@@ -35,6 +35,17 @@ st = fc.getTree().stats()
 a = acc_of(d)
 print(f"BH two_galaxies N={n}: {ms:.2f} ms/step, nodes {st['node_count']}, root mass {st['root_mass']:.1f} "
       f"(sum m {ic['mass'].astype(np.float64).sum():.1f}), finite {np.isfinite(a).all()}", flush=True)
+# parity at this size: 256 sampled bodies against the oracle's tree (same depth, same opening rule)
+import oracle_bind  # noqa: E402
+o = oracle_bind.load()
+hs = {k: getattr(d, k).cpu().numpy() for k in ("pos_x", "pos_y", "pos_z", "mass")}
+idx = np.linspace(0, n - 1, 256).astype(np.int64)
+r = o.barnes_hut_forces(hs["pos_x"], hs["pos_y"], hs["pos_z"], hs["mass"], idx, 1.0, float(np.float32(0.1) ** 2), 0.5)
+fc.computeForces(d)
+a = acc_of(d)
+ref = np.stack(r[:3], 1).astype(np.float64)
+err = np.linalg.norm(a[idx] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+print(f"   vs oracle tree on {idx.size} bodies: nodes {r[4]} (GPU {fc.getTree().getNodeCount()}), max rel err {err.max():.2e}", flush=True)
 del d, fc
 torch.cuda.empty_cache()
 n2 = 2 * n
@@ -48,3 +59,11 @@ ms = timed(lambda: integ.integrate(d, sh, 1e-3))
 a = acc_of(d)
 print(f"HASH uniform N={n2}: {ms:.2f} ms/step, cells {sh.getGrid().getTotalCells()}, finite {np.isfinite(a).all()}, "
       f"rms |a| {np.sqrt((a.astype(np.float64) ** 2).sum(1).mean()):.3f}", flush=True)
+hs = {k: getattr(d, k).cpu().numpy() for k in ("pos_x", "pos_y", "pos_z", "mass")}
+idx = np.linspace(0, n2 - 1, 128).astype(np.int64)
+sh.computeForces(d)
+a = acc_of(d)
+ref = np.stack(o.direct_cutoff_forces(hs["pos_x"], hs["pos_y"], hs["pos_z"], hs["mass"], idx, 1.0,
+                                      float(np.float32(0.01) ** 2), 1.0), 1).astype(np.float64)
+err = np.linalg.norm(a[idx] - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
+print(f"   vs all pairs within the cutoff (oracle) on {idx.size} bodies: max rel err {err.max():.2e}", flush=True)
