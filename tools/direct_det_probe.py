@@ -20,8 +20,10 @@ p = packed(ic)
 rng = np.random.default_rng(7)
 pg = p.clone()
 pg[:, 3] *= torch.from_numpy((0.75 + 0.5 * rng.random(n)).astype(np.float32)).cuda()
-for tpl in (16, 8):
-    ctx.tuning(3, tpl, 0)
+tpls = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (16, 8)
+splits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for tpl in tpls:
+    ctx.tuning(3, tpl, splits)
     for det in (True, False):
         ctx.deterministic(det)
         a = nb.time_direct_packed(ctx, p, p, 1.0, 1e-6, 3)
