@@ -635,6 +635,10 @@ class BarnesHutTree:
     def tuning(self, replicas: int = 0, split_level: int = 0):
         check(self.ctx._lib.nbody_hip_tree_tuning(self._h, replicas, split_level))
 
+    def walkWidth(self, targets_per_lane: int = 0):
+        """targets per lane of the walk without replicas: 0 automatic, 1, 2, 4 (nbody_hip_tree_walk_width)"""
+        check(self.ctx._lib.nbody_hip_tree_walk_width(self._h, targets_per_lane))
+
     def countVisits(self, enable: bool = True):
         """stats()["nodes_visited"] is only maintained when enabled (it costs a launch per walk)."""
         check(self.ctx._lib.nbody_hip_tree_count_visits(self._h, 1 if enable else 0))

@@ -57,6 +57,7 @@ constexpr int kStack = 8 * (kMaxDepth + 2);
 constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
 constexpr int kSplitAuto = 262144;     // automatic choice: replicas * n up to here (= 4096 waves)
 constexpr int kMaxReplicas = 16;
+constexpr int kWideAuto = 262144;      // bodies from which the pair walk is used (bh_traverse_pair_kernel)
 
 struct TreeRoot {
   float lo[3];
@@ -161,7 +162,35 @@ struct TreeArrays {
   int* child_last;  // id of the last child
   NodeRec* rec;     // 32-byte traversal record
   double4* m;       // fp64 monopole {com x, y, z, mass}
+  // the same records as PAIR BLOCKS for the pair walk (bh_traverse_pair_kernel): nodes 2i and 2i + 1 share a
+  // 48-byte block {cx cx, cy cy, cz cz, m m, s2 s2, link link}, so one s_load puts both nodes' values of a field
+  // into an aligned SGPR pair = one packed operand; a sibling group (consecutive ids) is <= 5 contiguous blocks.
+  //   m    : mass (0 for a leaf of several bodies: those interact body by body)
+  //   s2   : (2 half)^2; -1 for a leaf (always accepted, never opened)
+  //   link : internal node: first child | (children - 1) << 28 | kManyBit if one of the children is a leaf of
+  //          several bodies; one-body leaf: 0; leaf of several bodies: kManyLeaf
+  unsigned int* pb;
 };
+constexpr int kPairWords = 12;
+constexpr unsigned int kManyBit = 0x80000000u;
+constexpr unsigned int kManyLeaf = 0x70000000u;  // "eight children starting at node 0": not a possible link
+
+// (runs after tree_fill_kernel: first / last / child0 of every node are final)
+__device__ __forceinline__ void store_node(const TreeArrays& t, int nid, const NodeRec& r) {
+  t.rec[nid] = r;
+  const bool leaf = r.child == 0u;
+  unsigned int link = leaf ? (r.count == 1 ? 0u : kManyLeaf) : ((r.child & 0x0fffffffu) | (((r.child >> 28) - 1u) << 28));
+  if (!leaf) {
+    const int c0 = (int)(r.child & 0x0fffffffu), cn = (int)(r.child >> 28);
+    for (int c = c0; c < c0 + cn; c++)
+      if (t.child0[c] < 0 && t.last[c] - t.first[c] != 1) link |= kManyBit;
+  }
+  unsigned int* q = t.pb + (size_t)(nid >> 1) * kPairWords + (nid & 1);
+  q[0] = __float_as_uint(r.cx); q[2] = __float_as_uint(r.cy); q[4] = __float_as_uint(r.cz);
+  q[6] = __float_as_uint((leaf && r.count != 1) ? 0.f : r.mass);
+  q[8] = __float_as_uint(leaf ? -1.0f : r.size2);
+  q[10] = link;
+}
 
 // ---------------------------------------------------------------------------------------
 // Topology from the sorted keys alone, all levels at once.
@@ -315,7 +344,7 @@ __device__ __forceinline__ void monopole_level(int level, const int* __restrict_
     r.size2 = size * size;
     r.first = first; r.count = cnt;
     r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)nchild << 28));
-    t.rec[nid] = r;
+    store_node(t, nid, r);
   }
 }
 
@@ -438,10 +467,27 @@ __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __re
   r.size2 = size * size;
   r.first = first; r.count = cnt;
   r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
-  t.rec[nid] = r;
+  store_node(t, nid, r);
 }
 
 constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; [66..130] by lanes accepting
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// XCD-aware order of the walk's workgroups.  Workgroup b runs on XCD b % 8 (round-robin dispatch).  Neighbouring
+// walks fetch the same nodes, so they should sit behind the same L2: XCD x takes the chunks x, x + 8, x + 16, ...
+// of `chunk` consecutive workgroups (chunk = 0: one contiguous eighth per XCD).  A bijection for any nblk.
+__device__ __forceinline__ int xcd_block(int b, int nblk, int chunk) {
+  if (NBH_BH_XCD == 0) return b;
+  if (chunk <= 0) {
+    const int xcd = b % 8;
+    return xcd * (nblk / 8) + min(xcd, nblk % 8) + b / 8;
+  }
+  const int span = 8 * chunk, full = nblk / span * span;
+  if (b >= full) return b;  // the ragged end keeps its order
+  const int xcd = b % 8, r = b / 8;
+  return ((r / chunk) * 8 + xcd) * chunk + r % chunk;
+}
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -474,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
     const int* __restrict__ idx, int t_first, int n, float theta2, float eps2, float G,
     float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4,
-    unsigned long long* __restrict__ visit_count, int unit_max, double* __restrict__ partial) {
+    unsigned long long* __restrict__ visit_count, int unit_max, double* __restrict__ partial, int xcd_chunk) {
   // walks the sorted bodies [t_first, t_first + n) (a sharded run gives each rank a range)
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[4][kStack];
@@ -484,9 +530,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch); giving XCD x the x-th
   // contiguous eighth of the Morton-ordered targets keeps neighbouring walks -- which fetch the same
   // nodes -- behind the same L2
-  const int nblk = (int)gridDim.x, xcd = (int)blockIdx.x % 8;
-  int bid = xcd * (nblk / 8) + min(xcd, nblk % 8) + (int)blockIdx.x / 8;  // a bijection for any nblk
-  if (NBH_BH_XCD == 0) bid = (int)blockIdx.x;
+  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
   const int tl = bid * kBlock + tid;  // position in the range
   const int t = t_first + tl;                // position in the sorted body list
   const bool valid = tl < n;
@@ -606,6 +650,316 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   if (visit_count && lane == 0) atomicAdd(visit_count, visited);
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide walk (many bodies): one wave walks the tree for 64 * TPL Morton-adjacent bodies, each lane
+// holding TPL targets as packed pairs.  A node record is wave-uniform (SGPRs), so ONE packed
+// instruction (v_pk_add / v_pk_mul / v_pk_fma_f32) tests or applies it for two targets of a lane:
+// the distance chain, the opening threshold, the m * inv^3 chain and the three accumulations cost
+// the same issue slots for 128 targets as the plain walk spends on 64; only the compare, the rsq
+// and the select stay per target.  The union of the interaction lists of 128 neighbours is only a
+// little longer than that of 64 (the upper levels are shared), so the instructions per body drop.
+// Same per-body interaction list, same order of additions and same rounding as bh_traverse_kernel:
+// results are bit-identical to the plain walk.  Stack entry = (first child, count, TPL lane masks).
+// ---------------------------------------------------------------------------------------
+template <bool GUARD, int TPL>
+__global__ __launch_bounds__(kBlock) void bh_traverse_wide_kernel(
+    const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted, const int* __restrict__ idx, int t_first,
+    int n, float theta2, float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
+    float* __restrict__ acc_z, float4* __restrict__ acc4, unsigned long long* __restrict__ visit_count, int xcd_chunk) {
+#pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
+  static_assert(TPL == 2 || TPL == 4, "targets per lane");
+  constexpr int P = TPL / 2;
+  __shared__ int2 stk_c[4][kStack];
+  __shared__ unsigned long long stk_m[4][kStack][TPL];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
+  const int wave_first = (bid * 4 + w) * 64 * TPL;  // position in the range
+  int tl[TPL];
+  bool valid[TPL];
+  f2 px[P], py[P], pz[P];
+  unsigned long long M[TPL];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    float4 q[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int j = 2 * p + h;
+      tl[j] = wave_first + j * 64 + lane;
+      valid[j] = tl[j] < n;
+      q[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid[j]) q[h] = sorted[t_first + tl[j]];
+      M[j] = __ballot(valid[j]);
+    }
+    px[p] = f2{q[0].x, q[1].x}; py[p] = f2{q[0].y, q[1].y}; pz[p] = f2{q[0].z, q[1].z};
+  }
+  if (M[0] == 0ull) return;  // wave-uniform (the later runs of 64 are empty when the first is)
+  double sx[TPL], sy[TPL], sz[TPL];
+#pragma unroll
+  for (int j = 0; j < TPL; j++) sx[j] = sy[j] = sz[j] = 0.0;
+  if (lane == 0) {
+    stk_c[w][0] = make_int2(0, 1);
+#pragma unroll
+    for (int j = 0; j < TPL; j++) stk_m[w][0][j] = M[j];
+  }
+  int sp = 1;
+  __builtin_amdgcn_wave_barrier();
+  const f2 e2 = f2{eps2, eps2}, th2 = f2{theta2, theta2};
+  unsigned long long visited = 0;
+
+  while (sp > 0) {
+    sp--;
+    const int2 e = stk_c[w][sp];
+    const int c0 = rfl(e.x), cn = rfl(e.y);
+    visited += cn;
+#pragma unroll
+    for (int j = 0; j < TPL; j++) {
+      const unsigned long long m = stk_m[w][sp][j];
+      M[j] = ((unsigned long long)(unsigned)rfl((int)(m >> 32)) << 32) | (unsigned)rfl((int)(m & 0xffffffffull));
+    }
+    NodeRec rec[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) rec[k] = nodes[c0 + k];
+    f2 ax[P], ay[P], az[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) ax[p] = ay[p] = az[p] = f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k >= cn) break;  // wave-uniform
+      const NodeRec nd = rec[k];
+      if (nd.child == 0u) {
+        // leaf: its bodies interact individually (exact), the body itself is skipped (:175); a one-body
+        // leaf's record IS the body
+        const int q1 = nd.first + nd.count;
+        for (int q = nd.first; q < q1; q++) {
+          float4 s = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
+          if (nd.count != 1) s = sorted[q];
+#pragma unroll
+          for (int p = 0; p < P; p++) {
+            const f2 dx = s.x - px[p], dy = s.y - py[p], dz = s.z - pz[p];
+            const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            const f2 dd = d2 + e2;
+            const f2 inv = f2{__builtin_amdgcn_rsqf(dd.x), __builtin_amdgcn_rsqf(dd.y)};
+            const f2 fac = ((s.w * inv) * inv) * inv;
+            bool ok0 = __builtin_amdgcn_inverse_ballot_w64(M[2 * p]) && (q != t_first + tl[2 * p]);
+            bool ok1 = __builtin_amdgcn_inverse_ballot_w64(M[2 * p + 1]) && (q != t_first + tl[2 * p + 1]);
+            if (GUARD) { ok0 = ok0 && (d2.x > 0.f); ok1 = ok1 && (d2.y > 0.f); }
+            const f2 f = f2{ok0 ? fac.x : 0.f, ok1 ? fac.y : 0.f};
+            ax[p] = __builtin_elementwise_fma(f, dx, ax[p]);
+            ay[p] = __builtin_elementwise_fma(f, dy, ay[p]);
+            az[p] = __builtin_elementwise_fma(f, dz, az[p]);
+          }
+        }
+        continue;
+      }
+      unsigned long long open = 0ull, O[TPL];
+#pragma unroll
+      for (int p = 0; p < P; p++) {
+        const f2 dx = nd.cx - px[p], dy = nd.cy - py[p], dz = nd.cz - pz[p];
+        const f2 dist2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx)) + e2;  // :165
+        const f2 thr = th2 * dist2;  // :171-172 as size2 < theta2 * dist2
+        const unsigned long long F0 = __ballot(nd.size2 < thr.x), F1 = __ballot(nd.size2 < thr.y);
+        const f2 inv = f2{__builtin_amdgcn_rsqf(dist2.x), __builtin_amdgcn_rsqf(dist2.y)};
+        const f2 fac = ((nd.mass * inv) * inv) * inv;
+        const f2 f = f2{__builtin_amdgcn_inverse_ballot_w64(M[2 * p] & F0) ? fac.x : 0.f,
+                        __builtin_amdgcn_inverse_ballot_w64(M[2 * p + 1] & F1) ? fac.y : 0.f};
+        ax[p] = __builtin_elementwise_fma(f, dx, ax[p]);
+        ay[p] = __builtin_elementwise_fma(f, dy, ay[p]);
+        az[p] = __builtin_elementwise_fma(f, dz, az[p]);
+        O[2 * p] = M[2 * p] & ~F0;
+        O[2 * p + 1] = M[2 * p + 1] & ~F1;
+        open |= O[2 * p] | O[2 * p + 1];
+      }
+      if (open != 0ull) {
+        if (lane == 0) {
+          stk_c[w][sp] = make_int2((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28));
+#pragma unroll
+          for (int j = 0; j < TPL; j++) stk_m[w][sp][j] = O[j];
+        }
+        sp++;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      sx[2 * p] += (double)ax[p].x; sy[2 * p] += (double)ay[p].x; sz[2 * p] += (double)az[p].x;
+      sx[2 * p + 1] += (double)ax[p].y; sy[2 * p + 1] += (double)ay[p].y; sz[2 * p + 1] += (double)az[p].y;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < TPL; j++) {
+    if (!valid[j]) continue;
+    const int i = idx[t_first + tl[j]];
+    const float fx = (float)((double)G * sx[j]), fy = (float)((double)G * sy[j]), fz = (float)((double)G * sz[j]);
+    if (acc4) {
+      acc4[i] = make_float4(fx, fy, fz, 0.f);
+    } else {
+      acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
+    }
+  }
+  if (visit_count && lane == 0) atomicAdd(visit_count, visited);
+}
+
+// ---------------------------------------------------------------------------------------
+// Pair walk (the plain walk of many bodies).  Same wave-shared walk as bh_traverse_kernel, but the
+// siblings of a popped group are processed TWO AT A TIME: the node planes (TreeArrays::pcx ...) put
+// siblings (2j, 2j+1) into aligned SGPR pairs, so one packed instruction (v_pk_add / v_pk_mul /
+// v_pk_fma_f32) forms the distance chain, the opening threshold, the m inv^3 chain and the three
+// accumulations of both nodes for a lane's body; only the compare, the rsq and the select stay per node.
+// A leaf is an always-accepted node (size2 = -1) whose own body is removed from the accept mask with
+// scalar arithmetic (pself); leaves of several bodies (only at the depth limit or with leaf_max > 1) take
+// the body-by-body loop.  Interaction lists and the opening decisions are those of bh_traverse_kernel (same
+// rounding of every test); the fp32 sum of a sibling group is formed as (even siblings) + (odd siblings)
+// instead of in octant order, so results agree with the plain walk to fp32 rounding of a group sum.
+// ---------------------------------------------------------------------------------------
+typedef unsigned int u16v __attribute__((ext_vector_type(16), aligned(16)));
+typedef unsigned int u8v __attribute__((ext_vector_type(8), aligned(16)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4), aligned(16)));
+
+template <bool GUARD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void bh_traverse_pair_kernel(
+    TreeArrays tr, const float4* __restrict__ sorted, const int* __restrict__ idx, int t_first, int n, float theta2,
+    float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
+    float4* __restrict__ acc4, unsigned long long* __restrict__ visit_count, int xcd_chunk) {
+#pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
+  __shared__ int4 stk[WAVES][kStack];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
+  const int tl = bid * (WAVES * 64) + tid;
+  const int t = t_first + tl;
+  const bool valid = tl < n;
+  float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) pi = sorted[t];
+  const f2 px = f2{pi.x, pi.x}, py = f2{pi.y, pi.y}, pz = f2{pi.z, pi.z};
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  const unsigned long long m0 = __ballot(valid);
+  if (m0 == 0ull) return;  // wave-uniform
+  // entry = (first child, children | "a child is a leaf of several bodies" << 8, 64-bit lane mask)
+  if (lane == 0) stk[w][0] = make_int4(0, 1, (int)(unsigned)(m0 & 0xffffffffull), (int)(unsigned)(m0 >> 32));
+  int sp = 1;
+  __builtin_amdgcn_wave_barrier();
+  // eps^2 and theta^2 as packed VGPR constants (SGPRs are the scarce resource of this kernel)
+  float e2s, th2s;
+  asm("v_mov_b32 %0, %1" : "=v"(e2s) : "s"(eps2));
+  asm("v_mov_b32 %0, %1" : "=v"(th2s) : "s"(theta2));
+  const f2 e2 = f2{e2s, e2s}, th2 = f2{th2s, th2s};
+  unsigned long long visited = 0;
+
+  while (sp > 0) {
+    sp--;
+    const int4 e = stk[w][sp];
+    const unsigned int c0 = (unsigned int)rfl(e.x);
+    const int cnf = rfl(e.y), cn = cnf & 0xff;
+    const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.w) << 32) | (unsigned)rfl(e.z);
+    visited += cn;
+    // the group's pair blocks (ids c0 .. c0 + cn - 1 -> blocks c0 / 2 .. (c0 + cn - 1) / 2, at most five, one
+    // contiguous run): three always, the last two only for groups that reach them
+    const unsigned int fb = c0 >> 1;
+    const int nb = (int)(((c0 + (unsigned int)cn - 1u) >> 1) - fb) + 1;
+    const unsigned int* gp = tr.pb + (size_t)fb * kPairWords;
+    // three blocks up front; a group that reaches blocks 3 and 4 (six or more children) fetches them into the
+    // same registers once the first three are done: 36 instead of 60 SGPRs of node data keep the kernel at
+    // <= 80 SGPRs = 8 waves per SIMD (a walk is a chain of dependent fetches: waves in flight are its speed)
+    unsigned int blk[3 * kPairWords];
+    {
+      u16v v0 = *reinterpret_cast<const u16v*>(gp), v1 = *reinterpret_cast<const u16v*>(gp + 16);
+      u4v v2 = *reinterpret_cast<const u4v*>(gp + 32);
+      // (the empty asm pins every fetch up here: the compiler would otherwise sink the later blocks' loads to
+      // their first use, a second dependent memory round trip per group)
+      asm("" : "+s"(v0), "+s"(v1), "+s"(v2));
+#pragma unroll
+      for (int k = 0; k < 16; k++) { blk[k] = v0[k]; blk[16 + k] = v1[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) blk[32 + k] = v2[k];
+    }
+    // the first block's even node / the last block's odd node may belong to another group
+    const unsigned long long Mfirst = (c0 & 1u) ? 0ull : M;
+    const unsigned long long Mlast = ((c0 + (unsigned int)cn) & 1u) ? 0ull : M;
+    f2 ax = f2{0.f, 0.f}, ay = ax, az = ax;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      if (k >= nb) break;  // wave-uniform
+      if (k == 3) {
+        u16v v3 = *reinterpret_cast<const u16v*>(gp + 36);
+        u8v v4 = *reinterpret_cast<const u8v*>(gp + 52);
+        asm("" : "+s"(v3), "+s"(v4));
+#pragma unroll
+        for (int i = 0; i < 16; i++) blk[i] = v3[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) blk[16 + i] = v4[i];
+      }
+      const unsigned int* q = blk + (k % 3) * kPairWords;
+      const unsigned long long Ma = k == 0 ? Mfirst : M;
+      const unsigned long long Mb = k == nb - 1 ? Mlast : M;
+      const f2 dx = f2{__uint_as_float(q[0]), __uint_as_float(q[1])} - px,
+               dy = f2{__uint_as_float(q[2]), __uint_as_float(q[3])} - py,
+               dz = f2{__uint_as_float(q[4]), __uint_as_float(q[5])} - pz;
+      const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      const f2 dist2 = d2 + e2;      // :165
+      const f2 thr = th2 * dist2;    // :171-172 as size2 < theta2 * dist2
+      // "not >=": a NaN distance counts as far (the plain walk opens such a node down to the NaN body, which
+      // then spoils the same sums); leaves (size2 = -1) are far for every lane, so they are never opened
+      const unsigned long long Fa = __ballot(!(__uint_as_float(q[8]) >= thr.x)),
+                               Fb = __ballot(!(__uint_as_float(q[9]) >= thr.y));
+      const f2 inv = f2{__builtin_amdgcn_rsqf(dist2.x), __builtin_amdgcn_rsqf(dist2.y)};
+      const f2 fac = ((f2{__uint_as_float(q[6]), __uint_as_float(q[7])} * inv) * inv) * inv;
+      // the body's own leaf needs no exclusion (:175): d = 0 there, so it adds fac * 0 = 0 (fac is finite: eps^2 >=
+      // 1e-12 in this instantiation).  With eps ~ 0 (GUARD) every coincident body is dropped by the d2 > 0 test.
+      unsigned long long Aa = Ma & Fa, Ab = Mb & Fb;
+      if (GUARD) {
+        if ((int)q[8] < 0) Aa &= __ballot(d2.x > 0.f);
+        if ((int)q[9] < 0) Ab &= __ballot(d2.y > 0.f);
+      }
+      const f2 f = f2{__builtin_amdgcn_inverse_ballot_w64(Aa) ? fac.x : 0.f,
+                      __builtin_amdgcn_inverse_ballot_w64(Ab) ? fac.y : 0.f};
+      ax = __builtin_elementwise_fma(f, dx, ax);
+      ay = __builtin_elementwise_fma(f, dy, ay);
+      az = __builtin_elementwise_fma(f, dz, az);
+      const unsigned long long Oa = Ma & ~Fa, Ob = Mb & ~Fb;
+      if (Oa != 0ull) {
+        if (lane == 0)
+          stk[w][sp] = make_int4((int)(q[10] & 0x0fffffffu), (int)(((q[10] >> 28) & 7u) + 1u + ((q[10] >> 31) << 8)),
+                                 (int)(unsigned)(Oa & 0xffffffffull), (int)(unsigned)(Oa >> 32));
+        sp++;
+      }
+      if (Ob != 0ull) {
+        if (lane == 0)
+          stk[w][sp] = make_int4((int)(q[11] & 0x0fffffffu), (int)(((q[11] >> 28) & 7u) + 1u + ((q[11] >> 31) << 8)),
+                                 (int)(unsigned)(Ob & 0xffffffffull), (int)(unsigned)(Ob >> 32));
+        sp++;
+      }
+    }
+    if (cnf & 256) {  // leaves of several bodies (depth limit, leaf_max > 1): body by body, exact
+      const bool in = __builtin_amdgcn_inverse_ballot_w64(M);
+      for (int k = 0; k < cn; k++) {
+        const NodeRec nd = tr.rec[c0 + k];
+        if (nd.child != 0u || nd.count == 1) continue;
+        for (int q = nd.first; q < nd.first + nd.count; q++) {
+          const float4 s = sorted[q];
+          const float ex = s.x - pi.x, ey = s.y - pi.y, ez = s.z - pi.z;
+          const float q2 = bh_dist2(ex, ey, ez);
+          const float qi = __builtin_amdgcn_rsqf(q2 + eps2);
+          bool ok = in && (q != t);
+          if (GUARD) ok = ok && (q2 > 0.f);
+          const float g = ok ? ((s.w * qi) * qi) * qi : 0.f;
+          ax.x = __builtin_fmaf(g, ex, ax.x); ay.x = __builtin_fmaf(g, ey, ay.x); az.x = __builtin_fmaf(g, ez, az.x);
+        }
+      }
+    }
+    sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (valid) {
+    const int i = idx[t];
+    const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
+    if (acc4) {
+      acc4[i] = make_float4(fx, fy, fz, 0.f);
+    } else {
+      acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
+    }
+  }
+  if (visit_count && lane == 0) atomicAdd(visit_count, visited);
+}
+
 __global__ __launch_bounds__(kBlock) void bh_combine_kernel(const double* __restrict__ partial, int replicas,
                                                             const int* __restrict__ idx, int t_first, int n,
                                                             float G, float* __restrict__ acc_x,
@@ -660,6 +1014,7 @@ struct nbody_hip_tree {
   double* d_partial = nullptr;  // replicas x 3 x n fp64 partial sums (split traversal)
   double4* d_prefix = nullptr;  // kPrefixMax + 1 prefix sums of the sorted bodies (small trees)
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
+  int tune_width = 0;                           // targets per lane of the plain walk: 0 = automatic, 1, 2, 4
   bool count_visits = false;
   size_t built_count = 0;
 };
@@ -668,7 +1023,7 @@ static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                   g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl,
-                  g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m,
+                  g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix};
   for (void* p : ptrs) (void)hipFree(p);
   delete g;
@@ -682,7 +1037,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 // everything whose size depends on the tree shape: keys (32- or 64-bit), the level-major flag / scan
 // arrays, the sort / scan scratch and the node arrays
 static int tree_alloc_nodes(nbody_hip_tree* g) {
-  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m,
+  void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_keys_a, g->d_keys_b, g->d_flag, g->d_incl, g->d_tmp};
   for (void* p : ptrs) (void)hipFree(p);
   g->t = TreeArrays{};
@@ -722,6 +1077,8 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   if (e == hipSuccess) e = dmalloc(&g->t.rec, cap + 8);  // + 8: sibling-group prefetch reads ahead
   if (e == hipSuccess) e = hipMemset(g->t.rec, 0, (cap + 8) * sizeof(NodeRec));
   if (e == hipSuccess) e = dmalloc(&g->t.m, cap);
+  if (e == hipSuccess) e = dmalloc(&g->t.pb, (cap / 2 + 8) * kPairWords);  // + 8: group fetches read ahead
+  if (e == hipSuccess) e = hipMemset(g->t.pb, 0, (cap / 2 + 8) * kPairWords * sizeof(unsigned int));
   if (e != hipSuccess)
     return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
                     "Barnes-Hut tree allocation (%zu bodies, depth %d, %zu nodes): %s", n, g->max_depth, cap,
@@ -907,17 +1264,40 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   int unit_max = (int)(g->built_count / units);
   if (unit_max < 1) unit_max = 1;
   const bool guard = eps2 < 1e-12f;
+  static const int chunk = getenv("NBH_BH_CHUNK") ? atoi(getenv("NBH_BH_CHUNK")) : 0;  // experiment
+  // targets per lane of the plain walk: the wide walk pays once there are enough waves left to fill the chip
+  int wide = g->tune_width > 0 ? g->tune_width : (n >= kWideAuto ? 8 : 1);
 #define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
                      g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,                     \
-                     unit_max, g->d_partial)
-  if (K == 1 && visits) {  // counting on: the diagnostics instantiation (plain walk only)
+                     unit_max, g->d_partial, chunk)
+  if (K == 1 && visits && g->tune_width > 1) wide = g->tune_width;  // a forced width counts its own visits
+  else if (K == 1 && visits) wide = 1;
+  if (K == 1 && visits && wide == 1) {  // counting on: the diagnostics instantiation (plain walk only)
     if (guard) hipLaunchKernelGGL((bh_traverse_kernel<true, false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
                                   g->t.rec, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,
-                                  unit_max, g->d_partial);
+                                  unit_max, g->d_partial, chunk);
     else hipLaunchKernelGGL((bh_traverse_kernel<false, false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
                             g->t.rec, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,
-                            unit_max, g->d_partial);
+                            unit_max, g->d_partial, chunk);
+  } else if (K == 1 && wide > 1) {
+    const int wblocks = (n + kBlock * wide - 1) / (kBlock * wide);
+#define NBH_BH_WIDE(GD, W)                                                                                         \
+  hipLaunchKernelGGL((bh_traverse_wide_kernel<GD, W>), dim3(wblocks), dim3(kBlock), 0, ctx->stream, g->t.rec,      \
+                     g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits, chunk)
+    if (wide == 2) { if (guard) NBH_BH_WIDE(true, 2); else NBH_BH_WIDE(false, 2); }
+    else if (wide == 4) { if (guard) NBH_BH_WIDE(true, 4); else NBH_BH_WIDE(false, 4); }
+    else {
+      static const int pw = getenv("NBH_BH_PAIR_WAVES") ? atoi(getenv("NBH_BH_PAIR_WAVES")) : 4;  // experiment
+#define NBH_BH_PAIR(GD, W)                                                                                        \
+  hipLaunchKernelGGL((bh_traverse_pair_kernel<GD, W>), dim3((n + 64 * W - 1) / (64 * W)), dim3(64 * W), 0,        \
+                     ctx->stream, g->t, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4,    \
+                     visits, chunk)
+      if (pw == 1) { if (guard) NBH_BH_PAIR(true, 1); else NBH_BH_PAIR(false, 1); }
+      else { if (guard) NBH_BH_PAIR(true, 4); else NBH_BH_PAIR(false, 4); }
+#undef NBH_BH_PAIR
+    }
+#undef NBH_BH_WIDE
   } else if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
   } else {
@@ -978,6 +1358,15 @@ extern "C" int nbody_hip_tree_tuning(nbody_hip_tree* g, int replicas, int split_
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "replicas must be in [0, %d], units per replica in [0, 1024]", kMaxReplicas);
   g->tune_replicas = replicas;
   g->tune_split_level = split_level;
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_tree_walk_width(nbody_hip_tree* g, int targets_per_lane) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4 &&
+      targets_per_lane != 8)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "walk form must be 0 (automatic), 1, 2, 4 or 8");
+  g->tune_width = targets_per_lane;
   return NBODY_HIP_OK;
 }
 

@@ -1,4 +1,4 @@
-"""Barnes-Hut steps for rocprofv3 (kernel trace or counters): bh_small_trace.py [N] [steps] [ic name]"""
+"""Barnes-Hut steps for rocprofv3 (kernel trace or counters): bh_small_trace.py [N] [steps] [ic name] [walk form]"""
 import os
 import sys
 
@@ -18,5 +18,7 @@ fc = nb.BarnesHutCalculator(0.5)
 fc.setSofteningParameter(0.05)
 integ = nb.Integrator()
 fc.computeForces(d)
+if len(sys.argv) > 4:
+    fc.getTree().walkWidth(int(sys.argv[4]))
 integ.integrate_steps(d, fc, 1e-3, steps, graph=False)
 torch.cuda.synchronize()
