@@ -319,10 +319,10 @@ typedef struct nbody_hip_tree nbody_hip_tree;
  * Results are deterministic for a given setting; different settings differ by fp rounding only. */
 NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int units_per_replica);
 
-/* Targets per lane of the walk without replicas: 1 = one wave walks for 64 bodies, 2 / 4 = for 128 / 256
- * bodies with packed arithmetic (bit-identical results, fewer instructions per body; needs many bodies to
- * fill the chip); 0 = automatic (2 from 524,288 bodies). */
-NBODY_HIP_API int nbody_hip_tree_walk_width(nbody_hip_tree* tree, int targets_per_lane);
+/* Form of the walk without replicas: 1 = plain (one sibling node per step), 2 = pair walk (two sibling nodes per
+ * packed instruction, node records as pair blocks; same interaction lists, a sibling group's fp32 sum formed as
+ * (even siblings) + (odd siblings)); 0 = automatic (the pair walk). */
+NBODY_HIP_API int nbody_hip_tree_walk_form(nbody_hip_tree* tree, int form);
 /* Node-visit counting for nbody_hip_tree_stats (off by default: it costs a memset launch and an
  * atomic per wave in every walk). */
 NBODY_HIP_API int nbody_hip_tree_count_visits(nbody_hip_tree* tree, int enable);

@@ -113,7 +113,7 @@ PROTOTYPES = {
     "nbody_hip_tree_destroy": (C.c_int, [_P]),
     "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_tree_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
-    "nbody_hip_tree_walk_width": (C.c_int, [_P, C.c_int]),
+    "nbody_hip_tree_walk_form": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_visit_histogram": (C.c_int, [_P, C.POINTER(C.c_ulonglong * 130)]),
     "nbody_hip_tree_count_visits": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_build": (C.c_int, [_P, _PD]),

@@ -635,9 +635,9 @@ class BarnesHutTree:
     def tuning(self, replicas: int = 0, split_level: int = 0):
         check(self.ctx._lib.nbody_hip_tree_tuning(self._h, replicas, split_level))
 
-    def walkWidth(self, targets_per_lane: int = 0):
-        """targets per lane of the walk without replicas: 0 automatic, 1, 2, 4 (nbody_hip_tree_walk_width)"""
-        check(self.ctx._lib.nbody_hip_tree_walk_width(self._h, targets_per_lane))
+    def walkForm(self, form: int = 0):
+        """walk without replicas: 0 automatic, 1 plain, 2 pair walk (nbody_hip_tree_walk_form)"""
+        check(self.ctx._lib.nbody_hip_tree_walk_form(self._h, form))
 
     def countVisits(self, enable: bool = True):
         """stats()["nodes_visited"] is only maintained when enabled (it costs a launch per walk)."""

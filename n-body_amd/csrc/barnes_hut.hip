@@ -57,7 +57,6 @@ constexpr int kStack = 8 * (kMaxDepth + 2);
 constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
 constexpr int kSplitAuto = 262144;     // automatic choice: replicas * n up to here (= 4096 waves)
 constexpr int kMaxReplicas = 16;
-constexpr int kWideAuto = 262144;      // bodies from which the pair walk is used (bh_traverse_pair_kernel)
 
 struct TreeRoot {
   float lo[3];
@@ -474,19 +473,14 @@ constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; 
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// XCD-aware order of the walk's workgroups.  Workgroup b runs on XCD b % 8 (round-robin dispatch).  Neighbouring
-// walks fetch the same nodes, so they should sit behind the same L2: XCD x takes the chunks x, x + 8, x + 16, ...
-// of `chunk` consecutive workgroups (chunk = 0: one contiguous eighth per XCD).  A bijection for any nblk.
-__device__ __forceinline__ int xcd_block(int b, int nblk, int chunk) {
+// XCD-aware order of the walk's workgroups.  Workgroup b runs on XCD b % 8 (round-robin dispatch); giving XCD x
+// the x-th contiguous eighth of the Morton-ordered targets keeps neighbouring walks -- which fetch the same nodes
+// -- behind the same L2 (interleaving chunks of 1 .. 256 workgroups instead was measured: same or slower).
+// A bijection for any nblk.
+__device__ __forceinline__ int xcd_block(int b, int nblk) {
   if (NBH_BH_XCD == 0) return b;
-  if (chunk <= 0) {
-    const int xcd = b % 8;
-    return xcd * (nblk / 8) + min(xcd, nblk % 8) + b / 8;
-  }
-  const int span = 8 * chunk, full = nblk / span * span;
-  if (b >= full) return b;  // the ragged end keeps its order
-  const int xcd = b % 8, r = b / 8;
-  return ((r / chunk) * 8 + xcd) * chunk + r % chunk;
+  const int xcd = b % 8;
+  return xcd * (nblk / 8) + min(xcd, nblk % 8) + b / 8;
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -520,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
     const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted,
     const int* __restrict__ idx, int t_first, int n, float theta2, float eps2, float G,
     float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4,
-    unsigned long long* __restrict__ visit_count, int unit_max, double* __restrict__ partial, int xcd_chunk) {
+    unsigned long long* __restrict__ visit_count, int unit_max, double* __restrict__ partial) {
   // walks the sorted bodies [t_first, t_first + n) (a sharded run gives each rank a range)
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[4][kStack];
@@ -530,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
   // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch); giving XCD x the x-th
   // contiguous eighth of the Morton-ordered targets keeps neighbouring walks -- which fetch the same
   // nodes -- behind the same L2
-  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
+  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
   const int tl = bid * kBlock + tid;  // position in the range
   const int t = t_first + tl;                // position in the sorted body list
   const bool valid = tl < n;
@@ -651,155 +645,6 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Wide walk (many bodies): one wave walks the tree for 64 * TPL Morton-adjacent bodies, each lane
-// holding TPL targets as packed pairs.  A node record is wave-uniform (SGPRs), so ONE packed
-// instruction (v_pk_add / v_pk_mul / v_pk_fma_f32) tests or applies it for two targets of a lane:
-// the distance chain, the opening threshold, the m * inv^3 chain and the three accumulations cost
-// the same issue slots for 128 targets as the plain walk spends on 64; only the compare, the rsq
-// and the select stay per target.  The union of the interaction lists of 128 neighbours is only a
-// little longer than that of 64 (the upper levels are shared), so the instructions per body drop.
-// Same per-body interaction list, same order of additions and same rounding as bh_traverse_kernel:
-// results are bit-identical to the plain walk.  Stack entry = (first child, count, TPL lane masks).
-// ---------------------------------------------------------------------------------------
-template <bool GUARD, int TPL>
-__global__ __launch_bounds__(kBlock) void bh_traverse_wide_kernel(
-    const NodeRec* __restrict__ nodes, const float4* __restrict__ sorted, const int* __restrict__ idx, int t_first,
-    int n, float theta2, float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y,
-    float* __restrict__ acc_z, float4* __restrict__ acc4, unsigned long long* __restrict__ visit_count, int xcd_chunk) {
-#pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
-  static_assert(TPL == 2 || TPL == 4, "targets per lane");
-  constexpr int P = TPL / 2;
-  __shared__ int2 stk_c[4][kStack];
-  __shared__ unsigned long long stk_m[4][kStack][TPL];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
-  const int wave_first = (bid * 4 + w) * 64 * TPL;  // position in the range
-  int tl[TPL];
-  bool valid[TPL];
-  f2 px[P], py[P], pz[P];
-  unsigned long long M[TPL];
-#pragma unroll
-  for (int p = 0; p < P; p++) {
-    float4 q[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int j = 2 * p + h;
-      tl[j] = wave_first + j * 64 + lane;
-      valid[j] = tl[j] < n;
-      q[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid[j]) q[h] = sorted[t_first + tl[j]];
-      M[j] = __ballot(valid[j]);
-    }
-    px[p] = f2{q[0].x, q[1].x}; py[p] = f2{q[0].y, q[1].y}; pz[p] = f2{q[0].z, q[1].z};
-  }
-  if (M[0] == 0ull) return;  // wave-uniform (the later runs of 64 are empty when the first is)
-  double sx[TPL], sy[TPL], sz[TPL];
-#pragma unroll
-  for (int j = 0; j < TPL; j++) sx[j] = sy[j] = sz[j] = 0.0;
-  if (lane == 0) {
-    stk_c[w][0] = make_int2(0, 1);
-#pragma unroll
-    for (int j = 0; j < TPL; j++) stk_m[w][0][j] = M[j];
-  }
-  int sp = 1;
-  __builtin_amdgcn_wave_barrier();
-  const f2 e2 = f2{eps2, eps2}, th2 = f2{theta2, theta2};
-  unsigned long long visited = 0;
-
-  while (sp > 0) {
-    sp--;
-    const int2 e = stk_c[w][sp];
-    const int c0 = rfl(e.x), cn = rfl(e.y);
-    visited += cn;
-#pragma unroll
-    for (int j = 0; j < TPL; j++) {
-      const unsigned long long m = stk_m[w][sp][j];
-      M[j] = ((unsigned long long)(unsigned)rfl((int)(m >> 32)) << 32) | (unsigned)rfl((int)(m & 0xffffffffull));
-    }
-    NodeRec rec[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) rec[k] = nodes[c0 + k];
-    f2 ax[P], ay[P], az[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) ax[p] = ay[p] = az[p] = f2{0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (k >= cn) break;  // wave-uniform
-      const NodeRec nd = rec[k];
-      if (nd.child == 0u) {
-        // leaf: its bodies interact individually (exact), the body itself is skipped (:175); a one-body
-        // leaf's record IS the body
-        const int q1 = nd.first + nd.count;
-        for (int q = nd.first; q < q1; q++) {
-          float4 s = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
-          if (nd.count != 1) s = sorted[q];
-#pragma unroll
-          for (int p = 0; p < P; p++) {
-            const f2 dx = s.x - px[p], dy = s.y - py[p], dz = s.z - pz[p];
-            const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-            const f2 dd = d2 + e2;
-            const f2 inv = f2{__builtin_amdgcn_rsqf(dd.x), __builtin_amdgcn_rsqf(dd.y)};
-            const f2 fac = ((s.w * inv) * inv) * inv;
-            bool ok0 = __builtin_amdgcn_inverse_ballot_w64(M[2 * p]) && (q != t_first + tl[2 * p]);
-            bool ok1 = __builtin_amdgcn_inverse_ballot_w64(M[2 * p + 1]) && (q != t_first + tl[2 * p + 1]);
-            if (GUARD) { ok0 = ok0 && (d2.x > 0.f); ok1 = ok1 && (d2.y > 0.f); }
-            const f2 f = f2{ok0 ? fac.x : 0.f, ok1 ? fac.y : 0.f};
-            ax[p] = __builtin_elementwise_fma(f, dx, ax[p]);
-            ay[p] = __builtin_elementwise_fma(f, dy, ay[p]);
-            az[p] = __builtin_elementwise_fma(f, dz, az[p]);
-          }
-        }
-        continue;
-      }
-      unsigned long long open = 0ull, O[TPL];
-#pragma unroll
-      for (int p = 0; p < P; p++) {
-        const f2 dx = nd.cx - px[p], dy = nd.cy - py[p], dz = nd.cz - pz[p];
-        const f2 dist2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx)) + e2;  // :165
-        const f2 thr = th2 * dist2;  // :171-172 as size2 < theta2 * dist2
-        const unsigned long long F0 = __ballot(nd.size2 < thr.x), F1 = __ballot(nd.size2 < thr.y);
-        const f2 inv = f2{__builtin_amdgcn_rsqf(dist2.x), __builtin_amdgcn_rsqf(dist2.y)};
-        const f2 fac = ((nd.mass * inv) * inv) * inv;
-        const f2 f = f2{__builtin_amdgcn_inverse_ballot_w64(M[2 * p] & F0) ? fac.x : 0.f,
-                        __builtin_amdgcn_inverse_ballot_w64(M[2 * p + 1] & F1) ? fac.y : 0.f};
-        ax[p] = __builtin_elementwise_fma(f, dx, ax[p]);
-        ay[p] = __builtin_elementwise_fma(f, dy, ay[p]);
-        az[p] = __builtin_elementwise_fma(f, dz, az[p]);
-        O[2 * p] = M[2 * p] & ~F0;
-        O[2 * p + 1] = M[2 * p + 1] & ~F1;
-        open |= O[2 * p] | O[2 * p + 1];
-      }
-      if (open != 0ull) {
-        if (lane == 0) {
-          stk_c[w][sp] = make_int2((int)(nd.child & 0x0fffffffu), (int)(nd.child >> 28));
-#pragma unroll
-          for (int j = 0; j < TPL; j++) stk_m[w][sp][j] = O[j];
-        }
-        sp++;
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-      sx[2 * p] += (double)ax[p].x; sy[2 * p] += (double)ay[p].x; sz[2 * p] += (double)az[p].x;
-      sx[2 * p + 1] += (double)ax[p].y; sy[2 * p + 1] += (double)ay[p].y; sz[2 * p + 1] += (double)az[p].y;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-#pragma unroll
-  for (int j = 0; j < TPL; j++) {
-    if (!valid[j]) continue;
-    const int i = idx[t_first + tl[j]];
-    const float fx = (float)((double)G * sx[j]), fy = (float)((double)G * sy[j]), fz = (float)((double)G * sz[j]);
-    if (acc4) {
-      acc4[i] = make_float4(fx, fy, fz, 0.f);
-    } else {
-      acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
-    }
-  }
-  if (visit_count && lane == 0) atomicAdd(visit_count, visited);
-}
-
-// ---------------------------------------------------------------------------------------
 // Pair walk (the plain walk of many bodies).  Same wave-shared walk as bh_traverse_kernel, but the
 // siblings of a popped group are processed TWO AT A TIME: the node planes (TreeArrays::pcx ...) put
 // siblings (2j, 2j+1) into aligned SGPR pairs, so one packed instruction (v_pk_add / v_pk_mul /
@@ -819,11 +664,11 @@ template <bool GUARD, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void bh_traverse_pair_kernel(
     TreeArrays tr, const float4* __restrict__ sorted, const int* __restrict__ idx, int t_first, int n, float theta2,
     float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
-    float4* __restrict__ acc4, unsigned long long* __restrict__ visit_count, int xcd_chunk) {
+    float4* __restrict__ acc4, unsigned long long* __restrict__ visit_count) {
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
   __shared__ int4 stk[WAVES][kStack];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
+  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
   const int tl = bid * (WAVES * 64) + tid;
   const int t = t_first + tl;
   const bool valid = tl < n;
@@ -1014,7 +859,7 @@ struct nbody_hip_tree {
   double* d_partial = nullptr;  // replicas x 3 x n fp64 partial sums (split traversal)
   double4* d_prefix = nullptr;  // kPrefixMax + 1 prefix sums of the sorted bodies (small trees)
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
-  int tune_width = 0;                           // targets per lane of the plain walk: 0 = automatic, 1, 2, 4
+  int tune_form = 0;                            // walk without replicas: 0 = automatic, 1 = plain, 2 = pair walk
   bool count_visits = false;
   size_t built_count = 0;
 };
@@ -1264,40 +1109,29 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   int unit_max = (int)(g->built_count / units);
   if (unit_max < 1) unit_max = 1;
   const bool guard = eps2 < 1e-12f;
-  static const int chunk = getenv("NBH_BH_CHUNK") ? atoi(getenv("NBH_BH_CHUNK")) : 0;  // experiment
-  // targets per lane of the plain walk: the wide walk pays once there are enough waves left to fill the chip
-  int wide = g->tune_width > 0 ? g->tune_width : (n >= kWideAuto ? 8 : 1);
+  // walk without replicas: the pair walk unless the plain one is asked for
+  int form = g->tune_form > 0 ? g->tune_form : 2;
 #define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
                      g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,                     \
-                     unit_max, g->d_partial, chunk)
-  if (K == 1 && visits && g->tune_width > 1) wide = g->tune_width;  // a forced width counts its own visits
-  else if (K == 1 && visits) wide = 1;
-  if (K == 1 && visits && wide == 1) {  // counting on: the diagnostics instantiation (plain walk only)
+                     unit_max, g->d_partial)
+  if (K == 1 && visits && g->tune_form != 2) form = 1;  // counting on: the diagnostics instantiation of the
+  if (K == 1 && visits && form == 1) {                  // plain walk (the pair walk visits the same nodes)
     if (guard) hipLaunchKernelGGL((bh_traverse_kernel<true, false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
                                   g->t.rec, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,
-                                  unit_max, g->d_partial, chunk);
+                                  unit_max, g->d_partial);
     else hipLaunchKernelGGL((bh_traverse_kernel<false, false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
                             g->t.rec, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,
-                            unit_max, g->d_partial, chunk);
-  } else if (K == 1 && wide > 1) {
-    const int wblocks = (n + kBlock * wide - 1) / (kBlock * wide);
-#define NBH_BH_WIDE(GD, W)                                                                                         \
-  hipLaunchKernelGGL((bh_traverse_wide_kernel<GD, W>), dim3(wblocks), dim3(kBlock), 0, ctx->stream, g->t.rec,      \
-                     g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits, chunk)
-    if (wide == 2) { if (guard) NBH_BH_WIDE(true, 2); else NBH_BH_WIDE(false, 2); }
-    else if (wide == 4) { if (guard) NBH_BH_WIDE(true, 4); else NBH_BH_WIDE(false, 4); }
-    else {
-      static const int pw = getenv("NBH_BH_PAIR_WAVES") ? atoi(getenv("NBH_BH_PAIR_WAVES")) : 4;  // experiment
-#define NBH_BH_PAIR(GD, W)                                                                                        \
-  hipLaunchKernelGGL((bh_traverse_pair_kernel<GD, W>), dim3((n + 64 * W - 1) / (64 * W)), dim3(64 * W), 0,        \
-                     ctx->stream, g->t, g->d_sorted, g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4,    \
-                     visits, chunk)
-      if (pw == 1) { if (guard) NBH_BH_PAIR(true, 1); else NBH_BH_PAIR(false, 1); }
-      else { if (guard) NBH_BH_PAIR(true, 4); else NBH_BH_PAIR(false, 4); }
-#undef NBH_BH_PAIR
-    }
-#undef NBH_BH_WIDE
+                            unit_max, g->d_partial);
+  } else if (K == 1 && form == 2) {
+    // one wave per workgroup: the dispatcher refills single wave slots (4-wave groups: +1.5 %, 16-wave: +7 %)
+    const int waves = (n + 63) / 64;
+    if (guard)
+      hipLaunchKernelGGL((bh_traverse_pair_kernel<true, 1>), dim3(waves), dim3(64), 0, ctx->stream, g->t, g->d_sorted,
+                         g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits);
+    else
+      hipLaunchKernelGGL((bh_traverse_pair_kernel<false, 1>), dim3(waves), dim3(64), 0, ctx->stream, g->t, g->d_sorted,
+                         g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits);
   } else if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
   } else {
@@ -1361,12 +1195,10 @@ extern "C" int nbody_hip_tree_tuning(nbody_hip_tree* g, int replicas, int split_
   return NBODY_HIP_OK;
 }
 
-extern "C" int nbody_hip_tree_walk_width(nbody_hip_tree* g, int targets_per_lane) {
+extern "C" int nbody_hip_tree_walk_form(nbody_hip_tree* g, int form) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
-  if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4 &&
-      targets_per_lane != 8)
-    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "walk form must be 0 (automatic), 1, 2, 4 or 8");
-  g->tune_width = targets_per_lane;
+  if (form < 0 || form > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "walk form must be 0 (automatic), 1 or 2");
+  g->tune_form = form;
   return NBODY_HIP_OK;
 }
 

@@ -268,38 +268,41 @@ def test_split_walk_equals_plain_walk(nb, ctx, n, eps, max_depth):
         tree.tuning(17, 0)
 
 
-# the wide walk (a lane holds 2 or 4 targets as packed pairs) gives every body the interaction list, the
-# order of additions and the rounding of the plain walk: bit-identical results, ragged sizes included
+# the pair walk (two siblings per packed instruction, node records as pair blocks) against the plain walk: the same
+# interaction lists, a sibling group summed as (even siblings) + (odd siblings) -> equal to fp32 rounding;
+# reproducible; ragged sizes, eps = 0 (coincident-body guard), depth-limited and wide leaves (body-by-body path)
 @pytest.mark.parametrize("n,eps,max_depth,leaf_max", [(40000, 0.02, 20, 1), (40001, 0.0, 20, 1), (3000, 0.05, 10, 1),
-                                                      (129, 0.05, 20, 1), (20000, 0.02, 3, 1), (20000, 0.01, 20, 8)])
-def test_wide_walk_equals_plain_walk_bitwise(nb, ctx, n, eps, max_depth, leaf_max):
+                                                      (129, 0.05, 20, 1), (20000, 0.02, 3, 1), (20000, 0.01, 20, 8),
+                                                      (20000, 0.0, 4, 1)])
+def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     ic = nb.ic.two_galaxies(n, seed=23)
     d, _ = to_device(nb, ic)
     tree = nb.BarnesHutTree(n)
     tree.setParams(max_depth, leaf_max)
     tree.build(d)
     tree.tuning(1, 0)
-    tree.walkWidth(1)
+    tree.walkForm(1)
     tree.computeForces(d, 0.5, 1.0, eps)
     plain = acc_of(d)
     assert np.isfinite(plain).all()
-    for width in (2, 4):
-        tree.walkWidth(width)
+    for form in (2, 0):
+        tree.walkForm(form)
         tree.computeForces(d, 0.5, 1.0, eps)
-        assert np.array_equal(acc_of(d), plain), width
-    # the pair walk (two siblings per packed instruction): same interaction lists, a sibling group summed as
-    # (even siblings) + (odd siblings) -> equal to fp32 rounding; reproducible
-    tree.walkWidth(8)
+        a = acc_of(d)
+        assert rel_err(a, plain).max() < 1e-5, form
+        tree.computeForces(d, 0.5, 1.0, eps)
+        assert np.array_equal(acc_of(d), a), form
+    # node visits are those of the plain walk
+    tree.walkForm(2)
+    tree.countVisits(True)
     tree.computeForces(d, 0.5, 1.0, eps)
-    a = acc_of(d)
-    assert rel_err(a, plain).max() < 1e-5
+    pair_visits = tree.stats()["nodes_visited"]
+    tree.walkForm(1)
     tree.computeForces(d, 0.5, 1.0, eps)
-    assert np.array_equal(acc_of(d), a)
-    tree.walkWidth(0)
-    tree.computeForces(d, 0.5, 1.0, eps)
-    assert rel_err(acc_of(d), plain).max() < 1e-5
+    assert tree.stats()["nodes_visited"] == pair_visits
+    tree.countVisits(False)
     with pytest.raises(nb.ValidationException):
-        tree.walkWidth(3)
+        tree.walkForm(3)
 
 
 # sizes on both sides of the automatic switch between the split and the plain walk

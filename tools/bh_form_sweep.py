@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Barnes-Hut walk: targets per lane (1 = 64 bodies per wave, 2 / 4 = 128 / 256 with packed arithmetic)
-vs walk time.  Usage: python tools/bh_width_sweep.py [N ...]"""
+"""Barnes-Hut walk without replicas: plain (1) vs pair walk (2), time and node visits per wave.
+Usage: python tools/bh_width_sweep.py [N ...]"""
 import os
 import sys
 import time
@@ -36,14 +36,14 @@ for n in sizes:
         tree.build(d)
         tree.tuning(1, 0)
         line = []
-        for width in (1, 2, 8):
-            tree.walkWidth(width)
+        for width in (1, 2):
+            tree.walkForm(width)
             ms = timeit(lambda: tree.computeForces(d, 0.5, 1.0, eps))
             tree.countVisits(True)
             tree.computeForces(d, 0.5, 1.0, eps)
             visits = tree.stats()["nodes_visited"]
             tree.countVisits(False)
-            waves = (n + 64 * (width % 8 or 1) - 1) // (64 * (width % 8 or 1))
-            line.append(f"width {width}: {ms:7.3f} ms, {visits / waves:7.0f} nodes/wave")
+            waves = (n + 63) // 64
+            line.append(f"form {width}: {ms:7.3f} ms, {visits / waves:7.0f} nodes/wave")
         print(f"{name:14s} N={n}: " + ", ".join(line), flush=True)
         del tree, d

@@ -19,6 +19,6 @@ fc.setSofteningParameter(0.05)
 integ = nb.Integrator()
 fc.computeForces(d)
 if len(sys.argv) > 4:
-    fc.getTree().walkWidth(int(sys.argv[4]))
+    fc.getTree().walkForm(int(sys.argv[4]))
 integ.integrate_steps(d, fc, 1e-3, steps, graph=False)
 torch.cuda.synchronize()

@@ -20,7 +20,7 @@ python3 tools/pmc_summarise.py "$OUT/prof_direct" "direct_sym_kernel<16, false, 
     echo "stats $w rc=$?"
   done )
 bash tools/profile_bh.sh "$OUT/prof_bh" > "$OUT/prof_bh.log" 2>&1; echo "profile bh rc=$?"
-python3 tools/pmc_kernel_summarise.py "$OUT/prof_bh" "bh_traverse_kernel<false, false, false>" "two_galaxies N=1048576 theta=0.5 eps=0.05" > "$OUT/pmc_bh.json"
+python3 tools/pmc_kernel_summarise.py "$OUT/prof_bh" "bh_traverse_pair_kernel<false, 1>" "two_galaxies N=1048576 theta=0.5 eps=0.05" > "$OUT/pmc_bh.json"
 bash tools/profile_hash.sh "$OUT/prof_hash" > "$OUT/prof_hash.log" 2>&1; echo "profile hash rc=$?"
 python3 tools/pmc_kernel_summarise.py "$OUT/prof_hash" hash_cell_force "uniform box N=4194304, cell = cutoff = 1" > "$OUT/pmc_hash.json"
 python3 tools/bh_mask_hist.py two_galaxies 2>/dev/null > "$OUT/bh_lane_participation.txt"
