@@ -40,6 +40,21 @@
 
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                              rocprim::default_config, nbh::kSortMergeLimit>;
+#ifndef NBH_BH_RADIX_BITS
+#define NBH_BH_RADIX_BITS 10
+#endif
+#if NBH_BH_RADIX_BITS > 0
+// 63-bit keys: digits of NBH_BH_RADIX_BITS bits per onesweep pass instead of the default 8 -- 60 key bits at the
+// default depth are six passes instead of eight (build 0.59 -> 0.54 ms at N = 2^20; 11 bits do not fit the LDS of
+// rocPRIM's histogram kernel)
+using SortConfig64 = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 8>,
+                                        NBH_BH_RADIX_BITS, rocprim::block_radix_rank_algorithm::match>,
+    nbh::kSortMergeLimit>;
+#else
+using SortConfig64 = SortConfig;
+#endif
 
 namespace nbh {
 
@@ -169,17 +184,21 @@ struct TreeArrays {
   //   link : internal node: first child | (children - 1) << 28 | kManyBit if one of the children is a leaf of
   //          several bodies; one-body leaf: 0; leaf of several bodies: kManyLeaf
   unsigned int* pb;
+  // leaves of several bodies only exist where a node may not be split: below level scan_from (the depth limit,
+  // or everywhere with leaf_max > 1) or when the node arrays overflowed (*node_total > capacity)
+  int scan_from, capacity;
+  const int* node_total;
 };
 constexpr int kPairWords = 12;
 constexpr unsigned int kManyBit = 0x80000000u;
 constexpr unsigned int kManyLeaf = 0x70000000u;  // "eight children starting at node 0": not a possible link
 
 // (runs after tree_fill_kernel: first / last / child0 of every node are final)
-__device__ __forceinline__ void store_node(const TreeArrays& t, int nid, const NodeRec& r) {
+__device__ __forceinline__ void store_node(const TreeArrays& t, int nid, int level, const NodeRec& r) {
   t.rec[nid] = r;
   const bool leaf = r.child == 0u;
   unsigned int link = leaf ? (r.count == 1 ? 0u : kManyLeaf) : ((r.child & 0x0fffffffu) | (((r.child >> 28) - 1u) << 28));
-  if (!leaf) {
+  if (!leaf && (level + 1 >= t.scan_from || *t.node_total > t.capacity)) {  // a child may be a leaf of several bodies
     const int c0 = (int)(r.child & 0x0fffffffu), cn = (int)(r.child >> 28);
     for (int c = c0; c < c0 + cn; c++)
       if (t.child0[c] < 0 && t.last[c] - t.first[c] != 1) link |= kManyBit;
@@ -343,7 +362,7 @@ __device__ __forceinline__ void monopole_level(int level, const int* __restrict_
     r.size2 = size * size;
     r.first = first; r.count = cnt;
     r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)nchild << 28));
-    store_node(t, nid, r);
+    store_node(t, nid, level, r);
   }
 }
 
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __re
   r.size2 = size * size;
   r.first = first; r.count = cnt;
   r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
-  store_node(t, nid, r);
+  store_node(t, nid, level, r);
 }
 
 constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; [66..130] by lanes accepting
@@ -903,7 +922,7 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   if (e == hipSuccess) {
     size_t t1 = 0, t2 = 0;
     if (g->wide())
-      e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, static_cast<unsigned long long*>(g->d_keys_a),
+      e = rocprim::radix_sort_pairs<SortConfig64>(nullptr, t1, static_cast<unsigned long long*>(g->d_keys_a),
                                                 static_cast<unsigned long long*>(g->d_keys_b), g->d_idx_a, g->d_idx_b,
                                                 n, 0, 63, g->ctx->stream);
     else
@@ -928,6 +947,9 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
     return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
                     "Barnes-Hut tree allocation (%zu bodies, depth %d, %zu nodes): %s", n, g->max_depth, cap,
                     hipGetErrorString(e));
+  g->t.scan_from = g->leaf_max > 1 ? 0 : g->max_depth;
+  g->t.capacity = g->capacity;
+  g->t.node_total = g->d_level_base + g->max_depth + 1;
   return NBODY_HIP_OK;
 }
 
@@ -1009,12 +1031,13 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   // topology of every level: keys, sort, flags, one scan, fill (see tree_flags_kernel)
   const int levels = g->max_depth + 1;
   const size_t total = (size_t)levels * n;
-  auto topology = [&](auto* ka, auto* kb, int key_bits) -> int {
+  auto topology = [&](auto* ka, auto* kb, int first_bit, int key_bits) -> int {
     using K = std::remove_pointer_t<decltype(ka)>;
     hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_root, ka, g->d_idx_a);
     NBH_LAUNCH_CHECK();
     size_t tmp = g->tmp_bytes;
-    NBH_HIP(rocprim::radix_sort_pairs<SortConfig>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, 0, key_bits, st));
+    using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
+    NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
                        g->d_flag, reinterpret_cast<unsigned int*>(g->d_idx_a));  // idx_a is free after the sort
@@ -1028,10 +1051,13 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     return NBODY_HIP_OK;
   };
   if (g->wide()) {
-    if (int rc = topology(static_cast<unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b), 63))
+    // only the 3 * max_depth leading bits of the 63 shape the tree (bodies that share them share a leaf of the
+    // deepest level, where the order is immaterial: such a leaf interacts body by body)
+    if (int rc = topology(static_cast<unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b),
+                          63 - 3 * g->max_depth, 63))
       return rc;
   } else {
-    if (int rc = topology(static_cast<unsigned int*>(g->d_keys_a), static_cast<unsigned int*>(g->d_keys_b), 30)) return rc;
+    if (int rc = topology(static_cast<unsigned int*>(g->d_keys_a), static_cast<unsigned int*>(g->d_keys_b), 0, 30)) return rc;
   }
   if (ni <= kPrefixMax) {
     // small tree: every node's monopole from the prefix sums of the sorted bodies (see above)
