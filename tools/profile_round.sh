@@ -26,4 +26,6 @@ python3 tools/pmc_kernel_summarise.py "$OUT/prof_hash" hash_cell_force "uniform 
 python3 tools/bh_mask_hist.py two_galaxies 2>/dev/null > "$OUT/bh_lane_participation.txt"
 python3 tools/bh_mask_hist.py plummer 2>/dev/null >> "$OUT/bh_lane_participation.txt"
 python3 tools/bh_depth_sweep.py 2>/dev/null > "$OUT/bh_depth_sweep.txt"
+python3 tools/bh_form_sweep.py 262144 524288 1048576 4194304 2>/dev/null > "$OUT/bh_walk_forms.txt"
+python3 tools/bh_build_time.py 1048576 4194304 2>/dev/null > "$OUT/bh_build_time.txt"
 echo done
