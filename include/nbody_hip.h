@@ -321,7 +321,8 @@ NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int 
 
 /* Form of the walk without replicas: 1 = plain (one sibling node per step), 2 = pair walk (two sibling nodes per
  * packed instruction, node records as pair blocks; same interaction lists, a sibling group's fp32 sum formed as
- * (even siblings) + (odd siblings)); 0 = automatic (the pair walk). */
+ * (even siblings) + (odd siblings)), its waves scheduled longest-first from the node visits the previous walk
+ * recorded; 3 = pair walk in plain order; 0 = automatic (2).  Results do not depend on the schedule. */
 NBODY_HIP_API int nbody_hip_tree_walk_form(nbody_hip_tree* tree, int form);
 /* Node-visit counting for nbody_hip_tree_stats (off by default: it costs a memset launch and an
  * atomic per wave in every walk). */

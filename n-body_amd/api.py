@@ -636,7 +636,7 @@ class BarnesHutTree:
         check(self.ctx._lib.nbody_hip_tree_tuning(self._h, replicas, split_level))
 
     def walkForm(self, form: int = 0):
-        """walk without replicas: 0 automatic, 1 plain, 2 pair walk (nbody_hip_tree_walk_form)"""
+        """walk without replicas: 0 automatic, 1 plain, 2 pair walk (cost-ordered), 3 pair walk in plain order"""
         check(self.ctx._lib.nbody_hip_tree_walk_form(self._h, form))
 
     def countVisits(self, enable: bool = True):

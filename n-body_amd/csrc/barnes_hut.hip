@@ -679,15 +679,37 @@ typedef unsigned int u16v __attribute__((ext_vector_type(16), aligned(16)));
 typedef unsigned int u8v __attribute__((ext_vector_type(8), aligned(16)));
 typedef unsigned int u4v __attribute__((ext_vector_type(4), aligned(16)));
 
+// Arguments in one struct = the kernel-argument segment.  The walk loop has no SGPR to spare (80 = 8 waves per
+// SIMD), so what only the epilogue needs (`cold` below) is NOT touched before the loop: it is read afterwards
+// through a laundered kernarg pointer, which keeps the compiler from preloading it into SGPRs at entry.
+struct PairArgs {
+  const unsigned int* pb;     // pair blocks
+  const NodeRec* rec;         // records (leaves of several bodies only)
+  const float4* sorted;
+  const int* order;           // cost-ordered schedule or null
+  int t_first, n;
+  float theta2, eps2;
+  // cold
+  const int* idx;
+  float* acc_x; float* acc_y; float* acc_z;
+  float4* acc4;
+  unsigned long long* visit_count;
+  int* cost_out;
+  float G;
+};
+
 template <bool GUARD, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void bh_traverse_pair_kernel(
-    TreeArrays tr, const float4* __restrict__ sorted, const int* __restrict__ idx, int t_first, int n, float theta2,
-    float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
-    float4* __restrict__ acc4, unsigned long long* __restrict__ visit_count) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void bh_traverse_pair_kernel(PairArgs a) {
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
+  const float4* __restrict__ sorted = a.sorted;
+  const int* __restrict__ order = a.order;
+  const int t_first = a.t_first, n = a.n;
+  const float theta2 = a.theta2, eps2 = a.eps2;
   __shared__ int4 stk[WAVES][kStack];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
+  // which 64 * WAVES bodies: the cost-ordered schedule of walk_order_kernel (-1 = padding), or the plain XCD order
+  const int bid = order ? order[blockIdx.x] : xcd_block((int)blockIdx.x, (int)gridDim.x);
+  if (bid < 0) return;
   const int tl = bid * (WAVES * 64) + tid;
   const int t = t_first + tl;
   const bool valid = tl < n;
@@ -719,7 +741,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     // contiguous run): three always, the last two only for groups that reach them
     const unsigned int fb = c0 >> 1;
     const int nb = (int)(((c0 + (unsigned int)cn - 1u) >> 1) - fb) + 1;
-    const unsigned int* gp = tr.pb + (size_t)fb * kPairWords;
+    const unsigned int* gp = a.pb + (size_t)fb * kPairWords;
     // three blocks up front; a group that reaches blocks 3 and 4 (six or more children) fetches them into the
     // same registers once the first three are done: 36 instead of 60 SGPRs of node data keep the kernel at
     // <= 80 SGPRs = 8 waves per SIMD (a walk is a chain of dependent fetches: waves in flight are its speed)
@@ -780,13 +802,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
       az = __builtin_elementwise_fma(f, dz, az);
       const unsigned long long Oa = Ma & ~Fa, Ob = Mb & ~Fb;
       if (Oa != 0ull) {
-        if (lane == 0)
+        // (every lane stores the same entry to the same address: no lane predicate to keep in SGPRs)
           stk[w][sp] = make_int4((int)(q[10] & 0x0fffffffu), (int)(((q[10] >> 28) & 7u) + 1u + ((q[10] >> 31) << 8)),
                                  (int)(unsigned)(Oa & 0xffffffffull), (int)(unsigned)(Oa >> 32));
         sp++;
       }
       if (Ob != 0ull) {
-        if (lane == 0)
+        // (every lane stores the same entry to the same address: no lane predicate to keep in SGPRs)
           stk[w][sp] = make_int4((int)(q[11] & 0x0fffffffu), (int)(((q[11] >> 28) & 7u) + 1u + ((q[11] >> 31) << 8)),
                                  (int)(unsigned)(Ob & 0xffffffffull), (int)(unsigned)(Ob >> 32));
         sp++;
@@ -795,7 +817,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     if (cnf & 256) {  // leaves of several bodies (depth limit, leaf_max > 1): body by body, exact
       const bool in = __builtin_amdgcn_inverse_ballot_w64(M);
       for (int k = 0; k < cn; k++) {
-        const NodeRec nd = tr.rec[c0 + k];
+        const NodeRec nd = a.rec[c0 + k];
         if (nd.child != 0u || nd.count == 1) continue;
         for (int q = nd.first; q < nd.first + nd.count; q++) {
           const float4 s = sorted[q];
@@ -812,16 +834,98 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
     __builtin_amdgcn_wave_barrier();
   }
+  // epilogue arguments, fetched now (see PairArgs)
+  const PairArgs* ka = (const PairArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm("" : "+s"(ka));
   if (valid) {
-    const int i = idx[t];
+    const int i = ka->idx[t];
+    const float G = ka->G;
     const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
+    float4* acc4 = ka->acc4;
     if (acc4) {
       acc4[i] = make_float4(fx, fy, fz, 0.f);
     } else {
-      acc_x[i] = fx; acc_y[i] = fy; acc_z[i] = fz;
+      ka->acc_x[i] = fx; ka->acc_y[i] = fy; ka->acc_z[i] = fz;
     }
   }
-  if (visit_count && lane == 0) atomicAdd(visit_count, visited);
+  if (lane == 0) {
+    if (int* cost_out = ka->cost_out) cost_out[bid * WAVES + w] = (int)visited;  // next walk's schedule
+    if (unsigned long long* visit_count = ka->visit_count) atomicAdd(visit_count, visited);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Cost-ordered schedule of the pair walk.  A wave's walk is one long dependent chain (~0.5 ms at N = 2^20, the
+// kernel lasts 2 1/2 of them) and walks differ in length by the local density, so with the plain order the
+// launch ends in a long tail of half-empty SIMDs.  Bodies move little in a step: the node visits every wave
+// recorded in the PREVIOUS walk (cost_out) predict this one.  walk_plan_kernel cuts the Morton order into eight
+// contiguous ranges of equal total cost, one per XCD (workgroup b runs on XCD b % 8; contiguous ranges keep
+// neighbouring walks behind one L2), capped at `cap` waves each; the waves of a range are then sorted by
+// decreasing cost (longest first) and walk_layout_kernel interleaves the eight lists into order[8 * cap]
+// (-1 = padding).  Results do not depend on the schedule.
+// ---------------------------------------------------------------------------------------
+constexpr int kPlanBlock = 1024;
+__global__ __launch_bounds__(kPlanBlock) void walk_plan_kernel(const int* __restrict__ cost, int waves, int cap,
+                                                               unsigned int* __restrict__ keys, int* __restrict__ vals,
+                                                               int* __restrict__ bounds /* 9 */) {
+  __shared__ unsigned long long part[kPlanBlock];
+  __shared__ int sb[9];
+  const int tid = threadIdx.x;
+  const int per = (waves + kPlanBlock - 1) / kPlanBlock;
+  const int i0 = min(waves, tid * per), i1 = min(waves, i0 + per);
+  unsigned long long sum = 0;
+  for (int i = i0; i < i1; i++) sum += (unsigned int)cost[i] + 1u;
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < kPlanBlock; off <<= 1) {  // inclusive scan of the chunk sums
+    const unsigned long long v = tid >= off ? part[tid - off] : 0ull;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const unsigned long long total = part[kPlanBlock - 1];
+  if (tid == 0) {
+    // bounds[x] = first wave of XCD x: the wave at which the running cost passes x / 8 of the total, moved so
+    // that no range exceeds cap and the rest still fits into the remaining ranges
+    sb[0] = 0;
+    for (int x = 1; x < 8; x++) {
+      const unsigned long long want = total / 8 * (unsigned long long)x;
+      int lo = 0, hi = kPlanBlock;  // first chunk whose inclusive sum exceeds want
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (part[mid] > want) hi = mid; else lo = mid + 1;
+      }
+      int c = min(lo, kPlanBlock - 1);
+      unsigned long long run = c > 0 ? part[c - 1] : 0ull;
+      int i = min(waves, c * per);
+      const int iend = min(waves, i + per);
+      while (i < iend && run + (unsigned int)cost[i] + 1u <= want) { run += (unsigned int)cost[i] + 1u; i++; }
+      i = max(i, sb[x - 1]);
+      i = min(i, sb[x - 1] + cap);
+      i = max(i, waves - (8 - x) * cap);
+      sb[x] = min(max(i, 0), waves);
+    }
+    sb[8] = waves;
+    for (int x = 0; x <= 8; x++) bounds[x] = sb[x];
+  }
+  __syncthreads();
+  for (int i = i0; i < i1; i++) {
+    int x = 0;
+    while (x < 7 && i >= sb[x + 1]) x++;
+    const unsigned int c = min((unsigned int)cost[i], 0x00ffffffu);
+    keys[i] = ((unsigned int)x << 24) | (0x00ffffffu - c);  // ascending key = XCD, then decreasing cost
+    vals[i] = i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void walk_layout_kernel(const int* __restrict__ sorted_waves,
+                                                             const int* __restrict__ bounds, int cap,
+                                                             int* __restrict__ order) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= 8 * cap) return;
+  const int x = b % 8, r = b / 8;
+  const int start = bounds[x], count = bounds[x + 1] - start;
+  order[b] = r < count ? sorted_waves[start + r] : -1;
 }
 
 __global__ __launch_bounds__(kBlock) void bh_combine_kernel(const double* __restrict__ partial, int replicas,
@@ -879,6 +983,16 @@ struct nbody_hip_tree {
   double4* d_prefix = nullptr;  // kPrefixMax + 1 prefix sums of the sorted bodies (small trees)
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
   int tune_form = 0;                            // walk without replicas: 0 = automatic, 1 = plain, 2 = pair walk
+  // cost-ordered schedule of the pair walk (walk_plan_kernel): node visits per wave of the previous walk
+  int* d_cost = nullptr;         // waves
+  unsigned int* d_okeys[2] = {nullptr, nullptr};
+  int* d_ovals[2] = {nullptr, nullptr};
+  int* d_order = nullptr;        // 8 * cap
+  int* d_bounds = nullptr;       // 9
+  void* d_otmp = nullptr;
+  size_t otmp_bytes = 0;
+  int cost_first = -1, cost_n = -1;  // the range the recorded costs belong to
+  bool tune_schedule = true;
   bool count_visits = false;
   size_t built_count = 0;
 };
@@ -888,7 +1002,8 @@ static void tree_release(nbody_hip_tree* g) {
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                   g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
-                  g->d_tmp, g->d_visits, g->d_partial, g->d_prefix};
+                  g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_okeys[0], g->d_okeys[1],
+                  g->d_ovals[0], g->d_ovals[1], g->d_order, g->d_bounds, g->d_otmp};
   for (void* p : ptrs) (void)hipFree(p);
   delete g;
 }
@@ -972,6 +1087,20 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   if (e == hipSuccess) e = dmalloc(&g->d_visits, kVisitWords);
   if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
   if (e == hipSuccess) e = dmalloc(&g->d_prefix, (size_t)kPrefixMax + 1);
+  {
+    const size_t waves = n / 64 + 1, cap = waves / 8 + waves / 32 + 8;
+    if (e == hipSuccess) e = dmalloc(&g->d_cost, waves);
+    for (int k = 0; k < 2; k++) {
+      if (e == hipSuccess) e = dmalloc(&g->d_okeys[k], waves);
+      if (e == hipSuccess) e = dmalloc(&g->d_ovals[k], waves);
+    }
+    if (e == hipSuccess) e = dmalloc(&g->d_order, 8 * cap);
+    if (e == hipSuccess) e = dmalloc(&g->d_bounds, 16);
+    if (e == hipSuccess)
+      e = rocprim::radix_sort_pairs(nullptr, g->otmp_bytes, g->d_okeys[0], g->d_okeys[1], g->d_ovals[0], g->d_ovals[1],
+                                    waves, 0, 27, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&g->d_otmp, g->otmp_bytes > 0 ? g->otmp_bytes : 16);
+  }
   if (e != hipSuccess) {
     tree_release(g);
     return NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
@@ -1152,12 +1281,30 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   } else if (K == 1 && form == 2) {
     // one wave per workgroup: the dispatcher refills single wave slots (4-wave groups: +1.5 %, 16-wave: +7 %)
     const int waves = (n + 63) / 64;
-    if (guard)
-      hipLaunchKernelGGL((bh_traverse_pair_kernel<true, 1>), dim3(waves), dim3(64), 0, ctx->stream, g->t, g->d_sorted,
-                         g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits);
-    else
-      hipLaunchKernelGGL((bh_traverse_pair_kernel<false, 1>), dim3(waves), dim3(64), 0, ctx->stream, g->t, g->d_sorted,
-                         g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits);
+    const int* order = nullptr;
+    int grid = waves;
+    if (g->tune_schedule && g->cost_first == first && g->cost_n == n && waves >= 2048) {
+      // the previous walk of this range recorded every wave's node visits: longest first, equal cost per XCD
+      const int cap = waves / 8 + waves / 32 + 8;
+      hipLaunchKernelGGL(walk_plan_kernel, dim3(1), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, waves, cap,
+                         g->d_okeys[0], g->d_ovals[0], g->d_bounds);
+      size_t tmp = g->otmp_bytes;
+      NBH_HIP(rocprim::radix_sort_pairs(g->d_otmp, tmp, g->d_okeys[0], g->d_okeys[1], g->d_ovals[0], g->d_ovals[1],
+                                        (size_t)waves, 0, 27, ctx->stream));
+      hipLaunchKernelGGL(walk_layout_kernel, dim3((8 * cap + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                         g->d_ovals[1], g->d_bounds, cap, g->d_order);
+      order = g->d_order;
+      grid = 8 * cap;
+    }
+    PairArgs pa;
+    pa.pb = g->t.pb; pa.rec = g->t.rec; pa.sorted = g->d_sorted; pa.order = order;
+    pa.t_first = first; pa.n = n; pa.theta2 = theta2; pa.eps2 = eps2;
+    pa.idx = g->d_idx_b; pa.acc_x = ax; pa.acc_y = ay; pa.acc_z = az; pa.acc4 = acc4;
+    pa.visit_count = visits; pa.cost_out = g->d_cost; pa.G = G;
+    if (guard) hipLaunchKernelGGL((bh_traverse_pair_kernel<true, 1>), dim3(grid), dim3(64), 0, ctx->stream, pa);
+    else hipLaunchKernelGGL((bh_traverse_pair_kernel<false, 1>), dim3(grid), dim3(64), 0, ctx->stream, pa);
+    g->cost_first = first;
+    g->cost_n = n;
   } else if (K == 1) {
     if (guard) NBH_BH_LAUNCH(true, false, dim3(blocks)); else NBH_BH_LAUNCH(false, false, dim3(blocks));
   } else {
@@ -1223,8 +1370,9 @@ extern "C" int nbody_hip_tree_tuning(nbody_hip_tree* g, int replicas, int split_
 
 extern "C" int nbody_hip_tree_walk_form(nbody_hip_tree* g, int form) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
-  if (form < 0 || form > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "walk form must be 0 (automatic), 1 or 2");
-  g->tune_form = form;
+  if (form < 0 || form > 3) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "walk form must be 0 (automatic), 1, 2 or 3");
+  g->tune_form = form == 3 ? 2 : form;
+  g->tune_schedule = form != 3;
   return NBODY_HIP_OK;
 }
 

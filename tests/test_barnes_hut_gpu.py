@@ -273,7 +273,7 @@ def test_split_walk_equals_plain_walk(nb, ctx, n, eps, max_depth):
 # reproducible; ragged sizes, eps = 0 (coincident-body guard), depth-limited and wide leaves (body-by-body path)
 @pytest.mark.parametrize("n,eps,max_depth,leaf_max", [(40000, 0.02, 20, 1), (40001, 0.0, 20, 1), (3000, 0.05, 10, 1),
                                                       (129, 0.05, 20, 1), (20000, 0.02, 3, 1), (20000, 0.01, 20, 8),
-                                                      (20000, 0.0, 4, 1)])
+                                                      (20000, 0.0, 4, 1), (300001, 0.02, 20, 1)])
 def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     ic = nb.ic.two_galaxies(n, seed=23)
     d, _ = to_device(nb, ic)
@@ -285,13 +285,16 @@ def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     tree.computeForces(d, 0.5, 1.0, eps)
     plain = acc_of(d)
     assert np.isfinite(plain).all()
-    for form in (2, 0):
+    first = None
+    for form in (3, 2, 0):  # 3: plain order; 2 / 0: the second call runs the cost-ordered schedule
         tree.walkForm(form)
         tree.computeForces(d, 0.5, 1.0, eps)
         a = acc_of(d)
         assert rel_err(a, plain).max() < 1e-5, form
         tree.computeForces(d, 0.5, 1.0, eps)
         assert np.array_equal(acc_of(d), a), form
+        first = a if first is None else first
+        assert np.array_equal(a, first), form  # the schedule does not change a bit
     # node visits are those of the plain walk
     tree.walkForm(2)
     tree.countVisits(True)
@@ -302,7 +305,7 @@ def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     assert tree.stats()["nodes_visited"] == pair_visits
     tree.countVisits(False)
     with pytest.raises(nb.ValidationException):
-        tree.walkForm(3)
+        tree.walkForm(4)
 
 
 # sizes on both sides of the automatic switch between the split and the plain walk

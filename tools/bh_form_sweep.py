@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Barnes-Hut walk without replicas: plain (1) vs pair walk (2), time and node visits per wave.
+"""Barnes-Hut walk without replicas: plain (1), pair walk in plain order (3), pair walk cost-ordered (2):
+time and node visits per wave.
 Usage: python tools/bh_width_sweep.py [N ...]"""
 import os
 import sys
@@ -36,7 +37,7 @@ for n in sizes:
         tree.build(d)
         tree.tuning(1, 0)
         line = []
-        for width in (1, 2):
+        for width in (1, 3, 2):
             tree.walkForm(width)
             ms = timeit(lambda: tree.computeForces(d, 0.5, 1.0, eps))
             tree.countVisits(True)
