@@ -860,16 +860,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
 // launch ends in a long tail of half-empty SIMDs.  Bodies move little in a step: the node visits every wave
 // recorded in the PREVIOUS walk (cost_out) predict this one.  walk_plan_kernel cuts the Morton order into eight
 // contiguous ranges of equal total cost, one per XCD (workgroup b runs on XCD b % 8; contiguous ranges keep
-// neighbouring walks behind one L2), capped at `cap` waves each; the waves of a range are then sorted by
-// decreasing cost (longest first) and walk_layout_kernel interleaves the eight lists into order[8 * cap]
-// (-1 = padding).  Results do not depend on the schedule.
+// neighbouring walks behind one L2), each at most `cap` waves long; walk_order_kernel (one workgroup per XCD)
+// orders a range by decreasing cost -- a counting sort over 256 cost classes: longest walks first, the order
+// inside a class is immaterial -- straight into the interleaved list order[8 * cap] (-1 = padding).  Results do
+// not depend on the schedule.
 // ---------------------------------------------------------------------------------------
 constexpr int kPlanBlock = 1024;
 __global__ __launch_bounds__(kPlanBlock) void walk_plan_kernel(const int* __restrict__ cost, int waves, int cap,
-                                                               unsigned int* __restrict__ keys, int* __restrict__ vals,
                                                                int* __restrict__ bounds /* 9 */) {
   __shared__ unsigned long long part[kPlanBlock];
-  __shared__ int sb[9];
   const int tid = threadIdx.x;
   const int per = (waves + kPlanBlock - 1) / kPlanBlock;
   const int i0 = min(waves, tid * per), i1 = min(waves, i0 + per);
@@ -883,11 +882,12 @@ __global__ __launch_bounds__(kPlanBlock) void walk_plan_kernel(const int* __rest
     part[tid] += v;
     __syncthreads();
   }
-  const unsigned long long total = part[kPlanBlock - 1];
   if (tid == 0) {
-    // bounds[x] = first wave of XCD x: the wave at which the running cost passes x / 8 of the total, moved so
-    // that no range exceeds cap and the rest still fits into the remaining ranges
-    sb[0] = 0;
+    // bounds[x] = first wave of XCD x: the chunk (of `per` waves) at which the running cost passes x / 8 of the
+    // total, moved so that no range exceeds cap and the rest still fits into the remaining ranges
+    const unsigned long long total = part[kPlanBlock - 1];
+    int prev = 0;
+    bounds[0] = 0;
     for (int x = 1; x < 8; x++) {
       const unsigned long long want = total / 8 * (unsigned long long)x;
       int lo = 0, hi = kPlanBlock;  // first chunk whose inclusive sum exceeds want
@@ -895,37 +895,51 @@ __global__ __launch_bounds__(kPlanBlock) void walk_plan_kernel(const int* __rest
         const int mid = (lo + hi) >> 1;
         if (part[mid] > want) hi = mid; else lo = mid + 1;
       }
-      int c = min(lo, kPlanBlock - 1);
-      unsigned long long run = c > 0 ? part[c - 1] : 0ull;
-      int i = min(waves, c * per);
-      const int iend = min(waves, i + per);
-      while (i < iend && run + (unsigned int)cost[i] + 1u <= want) { run += (unsigned int)cost[i] + 1u; i++; }
-      i = max(i, sb[x - 1]);
-      i = min(i, sb[x - 1] + cap);
+      int i = min(waves, lo * per);
+      i = max(i, prev);
+      i = min(i, prev + cap);
       i = max(i, waves - (8 - x) * cap);
-      sb[x] = min(max(i, 0), waves);
+      i = min(max(i, 0), waves);
+      bounds[x] = i;
+      prev = i;
     }
-    sb[8] = waves;
-    for (int x = 0; x <= 8; x++) bounds[x] = sb[x];
-  }
-  __syncthreads();
-  for (int i = i0; i < i1; i++) {
-    int x = 0;
-    while (x < 7 && i >= sb[x + 1]) x++;
-    const unsigned int c = min((unsigned int)cost[i], 0x00ffffffu);
-    keys[i] = ((unsigned int)x << 24) | (0x00ffffffu - c);  // ascending key = XCD, then decreasing cost
-    vals[i] = i;
+    bounds[8] = waves;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void walk_layout_kernel(const int* __restrict__ sorted_waves,
-                                                             const int* __restrict__ bounds, int cap,
-                                                             int* __restrict__ order) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= 8 * cap) return;
-  const int x = b % 8, r = b / 8;
-  const int start = bounds[x], count = bounds[x + 1] - start;
-  order[b] = r < count ? sorted_waves[start + r] : -1;
+constexpr int kCostClasses = 256;
+__global__ __launch_bounds__(kPlanBlock) void walk_order_kernel(const int* __restrict__ cost,
+                                                                const int* __restrict__ bounds, int cap,
+                                                                int* __restrict__ order) {
+  __shared__ int hist[kCostClasses];
+  __shared__ int lo_hi[2];
+  const int x = blockIdx.x, tid = threadIdx.x;
+  const int start = bounds[x], end = bounds[x + 1];
+  if (tid < kCostClasses) hist[tid] = 0;
+  if (tid == 0) { lo_hi[0] = 0x7fffffff; lo_hi[1] = 0; }
+  __syncthreads();
+  int lo = 0x7fffffff, hi = 0;
+  for (int i = start + tid; i < end; i += kPlanBlock) { lo = min(lo, cost[i]); hi = max(hi, cost[i]); }
+  atomicMin(&lo_hi[0], lo);
+  atomicMax(&lo_hi[1], hi);
+  __syncthreads();
+  lo = lo_hi[0];
+  const int span = max(lo_hi[1] - lo, 0) + 1;
+  auto cls = [&](int c) {  // class 0 = the most expensive
+    return (int)(((long long)(lo_hi[1] - c) * kCostClasses) / span);
+  };
+  for (int i = start + tid; i < end; i += kPlanBlock) atomicAdd(&hist[cls(cost[i])], 1);
+  __syncthreads();
+  if (tid == 0) {  // exclusive scan of 256 counters
+    int run = 0;
+    for (int k = 0; k < kCostClasses; k++) { const int c = hist[k]; hist[k] = run; run += c; }
+  }
+  __syncthreads();
+  for (int i = start + tid; i < end; i += kPlanBlock) {
+    const int r = atomicAdd(&hist[cls(cost[i])], 1);
+    order[r * 8 + x] = i;
+  }
+  for (int r = end - start + tid; r < cap; r += kPlanBlock) order[r * 8 + x] = -1;
 }
 
 __global__ __launch_bounds__(kBlock) void bh_combine_kernel(const double* __restrict__ partial, int replicas,
@@ -985,12 +999,8 @@ struct nbody_hip_tree {
   int tune_form = 0;                            // walk without replicas: 0 = automatic, 1 = plain, 2 = pair walk
   // cost-ordered schedule of the pair walk (walk_plan_kernel): node visits per wave of the previous walk
   int* d_cost = nullptr;         // waves
-  unsigned int* d_okeys[2] = {nullptr, nullptr};
-  int* d_ovals[2] = {nullptr, nullptr};
   int* d_order = nullptr;        // 8 * cap
   int* d_bounds = nullptr;       // 9
-  void* d_otmp = nullptr;
-  size_t otmp_bytes = 0;
   int cost_first = -1, cost_n = -1;  // the range the recorded costs belong to
   bool tune_schedule = true;
   bool count_visits = false;
@@ -1002,8 +1012,7 @@ static void tree_release(nbody_hip_tree* g) {
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                   g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
-                  g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_okeys[0], g->d_okeys[1],
-                  g->d_ovals[0], g->d_ovals[1], g->d_order, g->d_bounds, g->d_otmp};
+                  g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
   for (void* p : ptrs) (void)hipFree(p);
   delete g;
 }
@@ -1090,16 +1099,8 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   {
     const size_t waves = n / 64 + 1, cap = waves / 8 + waves / 32 + 8;
     if (e == hipSuccess) e = dmalloc(&g->d_cost, waves);
-    for (int k = 0; k < 2; k++) {
-      if (e == hipSuccess) e = dmalloc(&g->d_okeys[k], waves);
-      if (e == hipSuccess) e = dmalloc(&g->d_ovals[k], waves);
-    }
     if (e == hipSuccess) e = dmalloc(&g->d_order, 8 * cap);
     if (e == hipSuccess) e = dmalloc(&g->d_bounds, 16);
-    if (e == hipSuccess)
-      e = rocprim::radix_sort_pairs(nullptr, g->otmp_bytes, g->d_okeys[0], g->d_okeys[1], g->d_ovals[0], g->d_ovals[1],
-                                    waves, 0, 27, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&g->d_otmp, g->otmp_bytes > 0 ? g->otmp_bytes : 16);
   }
   if (e != hipSuccess) {
     tree_release(g);
@@ -1287,12 +1288,9 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
       // the previous walk of this range recorded every wave's node visits: longest first, equal cost per XCD
       const int cap = waves / 8 + waves / 32 + 8;
       hipLaunchKernelGGL(walk_plan_kernel, dim3(1), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, waves, cap,
-                         g->d_okeys[0], g->d_ovals[0], g->d_bounds);
-      size_t tmp = g->otmp_bytes;
-      NBH_HIP(rocprim::radix_sort_pairs(g->d_otmp, tmp, g->d_okeys[0], g->d_okeys[1], g->d_ovals[0], g->d_ovals[1],
-                                        (size_t)waves, 0, 27, ctx->stream));
-      hipLaunchKernelGGL(walk_layout_kernel, dim3((8 * cap + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
-                         g->d_ovals[1], g->d_bounds, cap, g->d_order);
+                         g->d_bounds);
+      hipLaunchKernelGGL(walk_order_kernel, dim3(8), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, g->d_bounds, cap,
+                         g->d_order);
       order = g->d_order;
       grid = 8 * cap;
     }
