@@ -35,6 +35,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -236,7 +238,7 @@ __device__ __forceinline__ int side_extent(const K* __restrict__ keys, int i, in
 template <class K>
 __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict__ keys,
                                                             int n, int max_depth, int leaf_max,
-                                                            int* __restrict__ flag, unsigned int* __restrict__ lvlmask) {
+                                                            unsigned int* __restrict__ lvlmask) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const K k = keys[i];
@@ -255,10 +257,24 @@ __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict_
       open = a + b >= leaf_max;  // parent holds at least a + b + 1 > leaf_max bodies
     }
     const bool node = open && (d >> shift) != 0;
-    flag[(size_t)L * n + i] = node ? 1 : 0;
     if (node) mask |= 1u << L;
   }
-  lvlmask[i] = mask;  // levels at which body i heads a node: the fill pass walks these bits only
+  // levels at which body i heads a node: bit L = the flag of entry (L, i) of the level-major flag array.  The array
+  // itself is never written: the scan reads it through LevelFlag, the fill pass walks the set bits only.
+  lvlmask[i] = mask;
+}
+
+// entry e = L * n + i of the level-major flag array, read from the per-body level masks (the scan's input)
+struct LevelFlag {
+  const unsigned int* lvlmask;
+  unsigned int n;
+  __host__ __device__ int operator()(unsigned int e) const {
+    const unsigned int L = e / n, i = e - L * n;
+    return (int)((lvlmask[i] >> L) & 1u);
+  }
+};
+__host__ __device__ inline auto level_flags(const unsigned int* lvlmask, unsigned int n) {
+  return rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u), LevelFlag{lvlmask, n});
 }
 
 // One thread per BODY: it fills the nodes this body heads (the set bits of its level mask; 1.3 nodes per
@@ -988,7 +1004,7 @@ struct nbody_hip_tree {
   bool wide() const { return max_depth > kDepth32; }
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
-  int *d_flag = nullptr, *d_incl = nullptr;  // (max_depth + 1) * max_particles each, level-major
+  int* d_incl = nullptr;  // (max_depth + 1) * max_particles, level-major: inclusive scan of the node flags
   TreeArrays t{};
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -1010,7 +1026,7 @@ struct nbody_hip_tree {
 static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
-                  g->d_idx_b, g->d_sorted, g->d_flag, g->d_incl,
+                  g->d_idx_b, g->d_sorted, g->d_incl,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
   for (void* p : ptrs) (void)hipFree(p);
@@ -1026,11 +1042,11 @@ static hipError_t dmalloc(T** p, size_t count) {
 // arrays, the sort / scan scratch and the node arrays
 static int tree_alloc_nodes(nbody_hip_tree* g) {
   void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
-                  g->d_keys_a, g->d_keys_b, g->d_flag, g->d_incl, g->d_tmp};
+                  g->d_keys_a, g->d_keys_b, g->d_incl, g->d_tmp};
   for (void* p : ptrs) (void)hipFree(p);
   g->t = TreeArrays{};
   g->d_keys_a = g->d_keys_b = nullptr;
-  g->d_flag = g->d_incl = nullptr;
+  g->d_incl = nullptr;
   g->d_tmp = nullptr;
   const size_t n = g->max_particles;
   // leaves <= n; internal nodes per level <= n / (leaf_max + 1)
@@ -1041,7 +1057,6 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   const size_t nflag = (size_t)(g->max_depth + 1) * n;
   hipError_t e = hipMalloc(&g->d_keys_a, kbytes);
   if (e == hipSuccess) e = hipMalloc(&g->d_keys_b, kbytes);
-  if (e == hipSuccess) e = dmalloc(&g->d_flag, nflag);
   if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
   if (e == hipSuccess) {
     size_t t1 = 0, t2 = 0;
@@ -1054,7 +1069,8 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
                                                 static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
                                                 30, g->ctx->stream);
     if (e == hipSuccess)
-      e = rocprim::inclusive_scan(nullptr, t2, g->d_flag, g->d_incl, nflag, rocprim::plus<int>(), g->ctx->stream);
+      e = rocprim::inclusive_scan(nullptr, t2, level_flags(nullptr, (unsigned int)n), g->d_incl, nflag,
+                                  rocprim::plus<int>(), g->ctx->stream);
     g->tmp_bytes = t1 > t2 ? t1 : t2;
     if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
   }
@@ -1169,11 +1185,13 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
     NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
+    unsigned int* lvlmask = reinterpret_cast<unsigned int*>(g->d_idx_a);  // idx_a is free after the sort
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       g->d_flag, reinterpret_cast<unsigned int*>(g->d_idx_a));  // idx_a is free after the sort
+                       lvlmask);
     NBH_LAUNCH_CHECK();
     tmp = g->tmp_bytes;
-    NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, g->d_flag, g->d_incl, total, rocprim::plus<int>(), st));
+    NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, level_flags(lvlmask, (unsigned int)ni), g->d_incl, total,
+                                    rocprim::plus<int>(), st));
     hipLaunchKernelGGL(tree_fill_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
                        reinterpret_cast<const unsigned int*>(g->d_idx_a), g->d_incl, g->t, g->capacity,
                        g->d_level_base);
