@@ -308,6 +308,30 @@ def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
         tree.walkForm(4)
 
 
+# non-finite positions (a blown-up run) must not hang or fault the walk: a NaN / inf body spoils the monopoles above
+# it, and the sums that use them, but every form of the walk terminates (the pair walk counts a NaN distance as
+# "far", the plain walk opens down to the leaf) and a later build of finite bodies is clean again
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_walk_survives_non_finite_positions(nb, ctx, bad):
+    n = 150000
+    ic = nb.ic.plummer(n, seed=5)
+    ic["pos_x"][1234] = bad
+    ic["pos_z"][77777] = -bad
+    d, _ = to_device(nb, ic)
+    tree = nb.BarnesHutTree(n)
+    tree.build(d)
+    for form in (1, 2, 2, 3):
+        tree.walkForm(form)
+        tree.computeForces(d, 0.5, 1.0, 0.01)
+        assert acc_of(d).shape == (n, 3)
+    good = nb.ic.plummer(n, seed=5)
+    d2, _ = to_device(nb, good)
+    tree.walkForm(0)
+    tree.build(d2)
+    tree.computeForces(d2, 0.5, 1.0, 0.01)
+    assert np.isfinite(acc_of(d2)).all()
+
+
 # sizes on both sides of the automatic switch between the split and the plain walk
 @pytest.mark.parametrize("n", [16384, 50000, 70000])
 def test_forces_match_oracle_tree_mid_sizes(nb, oracle, ctx, n):
