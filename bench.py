@@ -294,7 +294,7 @@ def other_roofline(a, nb, ps, torch, workload):
         tree.countVisits(False)
         visits = int(st["nodes_visited"])
         nbytes = 32.0 * visits + 16.0 * d.count  # 32-byte record per visit + the body itself
-        kernel = "bh_traverse_pair_kernel" if d.count > 131072 else "bh_traverse_kernel"  # few bodies: split walk
+        kernel = "bh_traverse_pair_kernel" if d.count >= 98304 else "bh_traverse_kernel"  # few bodies: split walk
         return {"kernel": kernel, "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0,
                 "unit": "GB/s", "frac": nbytes / t / 8e12, "traffic": None, "avg_kernel_ms": t * 1e3,
                 "node_visits_per_s": visits / t, "nodes": st["node_count"],

@@ -74,6 +74,7 @@ constexpr int kStack = 8 * (kMaxDepth + 2);
 constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
 constexpr int kSplitAuto = 262144;     // automatic choice: replicas * n up to here (= 4096 waves)
 constexpr int kMaxReplicas = 16;
+constexpr int kPairFrom = 98304;       // bodies from which the walk runs without replicas (tools/bh_split_vs_pair.py)
 
 struct TreeRoot {
   float lo[3];
@@ -1273,6 +1274,7 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
   int K = 1;
   while (K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitAuto) K *= 2;
+  if (n >= kPairFrom) K = 1;  // the pair walk (8 waves per SIMD, scheduled) overtakes two replicas from here
   if (g->tune_replicas > 0) {
     K = 1;
     while (K < g->tune_replicas && K < kMaxReplicas && (size_t)(2 * K) * (size_t)n <= (size_t)kSplitBudget) K *= 2;

@@ -332,8 +332,8 @@ def test_walk_survives_non_finite_positions(nb, ctx, bad):
     assert np.isfinite(acc_of(d2)).all()
 
 
-# sizes on both sides of the automatic switch between the split and the plain walk
-@pytest.mark.parametrize("n", [16384, 50000, 70000])
+# sizes on both sides of the automatic switches (prefix monopoles, replicas 4 -> 2, split walk -> pair walk)
+@pytest.mark.parametrize("n", [16384, 50000, 70000, 98303, 98304])
 def test_forces_match_oracle_tree_mid_sizes(nb, oracle, ctx, n):
     ic = nb.ic.two_galaxies(n, seed=8)
     d, _ = to_device(nb, ic)
