@@ -28,4 +28,6 @@ python3 tools/bh_mask_hist.py plummer 2>/dev/null >> "$OUT/bh_lane_participation
 python3 tools/bh_depth_sweep.py 2>/dev/null > "$OUT/bh_depth_sweep.txt"
 python3 tools/bh_form_sweep.py 262144 524288 1048576 4194304 2>/dev/null > "$OUT/bh_walk_forms.txt"
 python3 tools/bh_build_time.py 1048576 4194304 2>/dev/null > "$OUT/bh_build_time.txt"
+python3 tools/bh_split_vs_pair.py 2>/dev/null > "$OUT/bh_split_vs_pair.txt"
+python3 -m pytest tests/test_direct_gpu.py tests/test_barnes_hut_gpu.py -q -s -k "headline or config4" > "$OUT/headline_parity_and_config4_drift.log" 2>&1
 echo done
