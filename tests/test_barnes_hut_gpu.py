@@ -348,7 +348,7 @@ def test_forces_match_oracle_tree_mid_sizes(nb, oracle, ctx, n):
 
 
 # 8e: ranks walk disjoint ranges of the same (replicated) tree; together they give the whole walk
-@pytest.mark.parametrize("n,parts", [(300000, 4), (300000, 1), (9000, 3)])
+@pytest.mark.parametrize("n,parts", [(300000, 4), (300000, 1), (9000, 3), (600000, 2)])
 def test_range_walks_equal_whole_walk(nb, ctx, n, parts):
     import ctypes as C
     from gpu_util import packed
@@ -372,10 +372,14 @@ def test_range_walks_equal_whole_walk(nb, ctx, n, parts):
         got = out.cpu().numpy()
         assert np.isfinite(got).all()            # every row written by some range
         assert (got[:, 3] == 0).all()
-        if n // parts > 262144 // 2:              # plain walk on both sides: bit for bit
+        if n // parts >= 98304:                   # the walk without replicas on both sides: bit for bit
             assert np.array_equal(got[:, :3], whole)
         else:                                     # the split walk's replica count depends on the range length
             assert rel_err(got[:, :3], whole).max() < 5e-6
+        # a rank walks the same range every step: the second walk of a range runs the cost-ordered schedule
+        lo, hi = cuts[-2], cuts[-1]
+        check(lib.nbody_hip_tree_compute_forces_packed(h, lo, hi - lo, 0.5, 1.0, 0.05, out.data_ptr()))
+        assert np.array_equal(out.cpu().numpy(), got)
         with pytest.raises(nb.ValidationException):
             check(lib.nbody_hip_tree_compute_forces_packed(h, n - 5, 6, 0.5, 1.0, 0.05, out.data_ptr()))
         check(lib.nbody_hip_tree_compute_forces_packed(h, n, 0, 0.5, 1.0, 0.05, out.data_ptr()))  # empty range: no-op
