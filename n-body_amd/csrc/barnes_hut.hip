@@ -681,16 +681,19 @@ __global__ __launch_bounds__(kBlock) void bh_traverse_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Pair walk (the plain walk of many bodies).  Same wave-shared walk as bh_traverse_kernel, but the
-// siblings of a popped group are processed TWO AT A TIME: the node planes (TreeArrays::pcx ...) put
-// siblings (2j, 2j+1) into aligned SGPR pairs, so one packed instruction (v_pk_add / v_pk_mul /
-// v_pk_fma_f32) forms the distance chain, the opening threshold, the m inv^3 chain and the three
-// accumulations of both nodes for a lane's body; only the compare, the rsq and the select stay per node.
-// A leaf is an always-accepted node (size2 = -1) whose own body is removed from the accept mask with
-// scalar arithmetic (pself); leaves of several bodies (only at the depth limit or with leaf_max > 1) take
-// the body-by-body loop.  Interaction lists and the opening decisions are those of bh_traverse_kernel (same
-// rounding of every test); the fp32 sum of a sibling group is formed as (even siblings) + (odd siblings)
-// instead of in octant order, so results agree with the plain walk to fp32 rounding of a group sum.
+// Pair walk (the walk without replicas, from kPairFrom bodies).  Same wave-shared walk as bh_traverse_kernel,
+// but the siblings of a popped group are processed TWO AT A TIME: the pair blocks (TreeArrays::pb) put nodes
+// (2i, 2i+1) into aligned SGPR pairs, so one packed instruction (v_pk_add / v_pk_mul / v_pk_fma_f32) forms the
+// distance chain, the opening threshold, the m inv^3 chain and the three accumulations of both nodes for a
+// lane's body; only the compare, the rsq and the select stay per node.  A group (consecutive ids c0 .. c0 + cn - 1)
+// is the blocks c0 / 2 .. (c0 + cn - 1) / 2; the first block's even node / the last block's odd node may belong
+// to a neighbouring group and are masked off.  A leaf is an always-accepted node (size2 = -1); its own body
+// needs no exclusion (d = 0 adds nothing); leaves of several bodies (only at the depth limit or with
+// leaf_max > 1) are flagged in their parent's link and take the body-by-body loop.  Interaction lists and the
+// opening decisions are those of bh_traverse_kernel (same rounding of every test); the fp32 sum of a sibling
+// group is formed as (even ids) + (odd ids) instead of in octant order, so results agree with the plain walk
+// to fp32 rounding of a group sum.  One wave per workgroup, 80 SGPRs (= 8 waves per SIMD: a walk is a chain of
+// dependent fetches, the waves in flight are its speed), schedule: walk_plan_kernel.
 // ---------------------------------------------------------------------------------------
 typedef unsigned int u16v __attribute__((ext_vector_type(16), aligned(16)));
 typedef unsigned int u8v __attribute__((ext_vector_type(8), aligned(16)));
