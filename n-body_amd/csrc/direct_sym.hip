@@ -21,9 +21,10 @@
 // across XCDs, measured ~180 G adds/s).  The I-side sums stay in registers for the whole kernel
 // (fp32 per 4 chunks, folded into fp64) and are added once at the end.
 //
-// Not bitwise reproducible (atomic order), unlike direct.hip; agreement with the oracle is the
-// same 1e-5.  Used for the single-GPU all-pairs case (targets == sources); the one-sided kernel
-// remains the path for rectangular target/source sets (sharded runs) and for eps^2 < 1e-12.
+// With the atomics the result depends on their order in the last bit; the DET form (default for all pairs, see
+// below) gives every contribution a slot of its own and is bitwise reproducible like direct.hip; agreement with
+// the oracle is the same 1e-5 either way.  Used for the single-GPU all-pairs case (targets == sources) and, as
+// RECT, for shard pairs; the one-sided kernel remains the path for N < 12,288 and for eps^2 < 1e-12.
 
 #include <type_traits>
 
