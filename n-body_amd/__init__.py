@@ -17,4 +17,13 @@ from .api import (BarnesHutCalculator, BarnesHutTree, Context, StepGraph, Direct
                   time_direct_packed)
 from .system import (MAX_PARTICLE_COUNT, NBODY_MAGIC, NBODY_VERSION, ParticleSystem,  # noqa: F401,E402
                      Serializer, SimulationState)
-from . import cli, observability  # noqa: F401,E402  (benchmarks: `python -m nbody_amd.benchmarks`, imported on demand)
+from . import observability  # noqa: F401,E402
+
+
+def __getattr__(name):
+    # `cli` and `benchmarks` are also `python -m` entry points: importing them here eagerly makes runpy warn
+    # ("found in sys.modules after import of package"), so they are loaded on first use (nb.cli, nb.benchmarks)
+    if name in ("cli", "benchmarks"):
+        import importlib
+        return importlib.import_module("." + name, __name__)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
