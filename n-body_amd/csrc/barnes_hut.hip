@@ -72,7 +72,7 @@ constexpr int kDefaultDepth = 20;  // the depth the reference's insertion loop s
                                    // (a = 0.1), whose depth-10 cells hold up to 1,600 bodies
 constexpr int kStack = 8 * (kMaxDepth + 2);
 constexpr int kSplitBudget = 2097152;  // capacity of the partial-sum buffer: replicas * n
-constexpr int kSplitAuto = 262144;     // automatic choice: replicas * n up to here (= 4096 waves)
+constexpr int kSplitAuto = 327680;     // automatic choice: replicas * n up to here (= 5120 waves; tools/bh_k_small.py)
 constexpr int kMaxReplicas = 16;
 constexpr int kPairFrom = 98304;       // bodies from which the walk runs without replicas (tools/bh_split_vs_pair.py)
 
