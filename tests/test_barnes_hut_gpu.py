@@ -308,6 +308,24 @@ def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
         tree.walkForm(4)
 
 
+# the cost-ordered schedule under extreme skew: a compact core inside a wide box (a few waves carry most of the
+# node visits, so the per-XCD ranges hit their caps); every body walked exactly once, bit for bit the plain order
+def test_pair_walk_schedule_skewed_costs(nb, ctx):
+    n = 400000
+    ic = nb.ic.plummer(n, seed=9, a=0.05, rmax=200.0)
+    d, _ = to_device(nb, ic)
+    tree = nb.BarnesHutTree(n)
+    tree.build(d)
+    tree.walkForm(3)
+    tree.computeForces(d, 0.5, 1.0, 1e-3)
+    plain_order = acc_of(d)
+    assert np.isfinite(plain_order).all()
+    tree.walkForm(2)
+    for _ in range(3):  # first call records the costs, the next ones are scheduled
+        tree.computeForces(d, 0.5, 1.0, 1e-3)
+        assert np.array_equal(acc_of(d), plain_order)
+
+
 # non-finite positions (a blown-up run) must not hang or fault the walk: a NaN / inf body spoils the monopoles above
 # it, and the sums that use them, but every form of the walk terminates (the pair walk counts a NaN distance as
 # "far", the plain walk opens down to the leaf) and a later build of finite bodies is clean again
