@@ -487,7 +487,7 @@ def main():
             ms_g = nb.time_direct_packed(ctx, pg, pg, G, eps2, a.kernel_iters)
             ach_g = FLOP_PER_PAIR * float(n) * n / (ms_g * 1e-3) / 1e12
             out["roofline"]["general_mass"] = {
-                "kernel": (f"nbh::direct_sym_kernel<{8 if (det and r == 16 and not a.tpl) else r},false,false,"
+                "kernel": (f"nbh::direct_sym_kernel<{12 if (det and r == 16 and not a.tpl) else r},false,false,"
                            f"{'true' if det else 'false'}>"), "launch_ms": ms_g, "achieved": ach_g,
                 "frac": ach_g / PEAK_FP32_VALU_TFLOPS, "pair_interactions_per_s_kernel": float(n) * n / (ms_g * 1e-3),
                 "note": "same positions, masses multiplied by U[0.75, 1.25)"}

@@ -386,7 +386,7 @@ NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_f
  * instead (their order varies from launch to launch: fp32 results differ in the last bit now and then).
  * The slots cost 24 (N / (512 R) + splits) bytes per body of workspace (3.4 GB at N = 2^20) and 0.2 % of
  * time for equal masses, 3.8 % for general masses (measured at N = 2^20: 155.0 vs 154.6 ms and 176.8 vs
- * 170.3 ms per launch; the general-mass kernel then keeps 8 bodies per lane instead of 16); above 24 GiB
+ * 170.3 ms per launch; the general-mass kernel then keeps 12 bodies per lane instead of 16); above 24 GiB
  * of slots (N > ~2.7 M) the atomic form is used regardless.  The one-sided kernel (N < 12,288, rectangular
  * sets) is reproducible anyway; the
  * two-set kernel of the sharded path keeps its atomics.  On by default. */
@@ -395,7 +395,7 @@ NBODY_HIP_API int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int enable)
 /* Tuning knobs for experiments.  variant: -1 automatic, 0 scalar body + LDS sources, 1 packed
  * (v_pk_*_f32) body + LDS sources, 2 scalar body + scalar-cache sources, 3 symmetric (action =
  * -reaction) kernel whenever targets == sources; the others 0 = automatic:
- * targets_per_lane: 1, 2 or 4 (6, 8: symmetric kernel only); source_splits: number of source sub-ranges per target block. */
+ * targets_per_lane: 1, 2 or 4 (6, 8, 12, 16: symmetric kernel only; 12: all pairs only); source_splits: number of source sub-ranges per target block. */
 NBODY_HIP_API int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targets_per_lane,
                             int source_splits);
 

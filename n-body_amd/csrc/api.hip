@@ -389,7 +389,7 @@ extern "C" int nbody_hip_direct_tuning(nbody_hip_ctx* ctx, int variant, int targ
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
   if (variant < -1 || variant > 3) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "variant must be -1 (auto), 0, 1, 2 or 3");
   if (targets_per_lane != 0 && targets_per_lane != 1 && targets_per_lane != 2 && targets_per_lane != 4 &&
-      targets_per_lane != 6 && targets_per_lane != 8 && targets_per_lane != 16)
+      targets_per_lane != 6 && targets_per_lane != 8 && targets_per_lane != 12 && targets_per_lane != 16)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "targets_per_lane must be 0 (auto), 1, 2, 4 (6, 8, 16: symmetric kernel only)");
   if (source_splits < 0 || source_splits > 4096)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "source_splits must be in [0, 4096]");

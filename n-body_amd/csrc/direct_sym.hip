@@ -362,7 +362,7 @@ bool symmetric_pays(const nbody_hip_ctx* ctx, size_t n) {
 // workgroups whatever R is, so it takes R = 16 much earlier than the half-ring all-pairs kernel
 static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
   if (ctx->tune_tpl == 2 || ctx->tune_tpl == 4 || ctx->tune_tpl == 6 || ctx->tune_tpl == 8 ||
-      ctx->tune_tpl == 16)
+      ctx->tune_tpl == 16 || (ctx->tune_tpl == 12 && !two_sets))
     return ctx->tune_tpl;
   if (two_sets) return n >= 49152 ? 16 : (n >= 16384 ? 8 : 4);
   return n >= 786432 ? 16 : (n >= 28000 ? 8 : 4);
@@ -404,6 +404,7 @@ void launch_all_pairs_R(nbody_hip_ctx* ctx, const SymShape& c, const float4* pos
     case 2: launch_all_pairs<2, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
     case 6: launch_all_pairs<6, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
     case 8: launch_all_pairs<8, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+    case 12: launch_all_pairs<12, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
     case 16: launch_all_pairs<16, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
     default: launch_all_pairs<4, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
   }
@@ -423,8 +424,10 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
   const bool det = ctx->deterministic &&
                    (size_t)(eq.D + eq.splits) * eq.plane * 3 * sizeof(double) <= kDetBudgetBytes;
   // general masses at 16 bodies per lane: the slot stores push the kernel from 277 to 285 registers (191 ms
-  // against 170 ms with atomics at N = 2^20); 8 bodies per lane run it in 177 ms (tools/direct_det_probe.py)
-  const SymShape gen = (det && eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, 8) : eq;
+  // against 170 ms with atomics at N = 2^20); 12 bodies per lane (248 registers, 78 KiB of LDS = two workgroups
+  // per CU) run it in 178 ms where 8 take 184 (tools/direct_det_probe.py, same box)
+  SymShape gen = (det && eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, 12) : eq;
+  if ((size_t)(gen.D + gen.splits) * gen.plane * 3 * sizeof(double) > kDetBudgetBytes) gen = eq;  // more slots: keep the budget
   const int nslots_eq = det ? eq.D + eq.splits : 1, nslots_gen = det ? gen.D + gen.splits : 1;
   const size_t bytes_eq = (size_t)nslots_eq * eq.plane * 3 * sizeof(double);
   const size_t bytes_gen = (size_t)nslots_gen * gen.plane * 3 * sizeof(double);
