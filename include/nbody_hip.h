@@ -385,7 +385,7 @@ NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_f
  * goes to a slot of its own and the slots are added in a fixed order.  enable = 0 switches to fp64 atomics
  * instead (their order varies from launch to launch: fp32 results differ in the last bit now and then).
  * The slots cost 24 (N / (512 R) + splits) bytes per body of workspace (3.4 GB at N = 2^20) and 0.2 % of
- * time for equal masses, 3.8 % for general masses (measured at N = 2^20: 155.0 vs 154.6 ms and 176.8 vs
+ * time for equal masses, 1 % for general masses (measured at N = 2^20: 155.0 vs 154.6 ms and 171.9 vs
  * 170.3 ms per launch; the general-mass kernel then keeps 12 bodies per lane instead of 16); above 24 GiB
  * of slots (N > ~2.7 M) the atomic form is used regardless.  The one-sided kernel (N < 12,288, rectangular
  * sets) is reproducible anyway; the
