@@ -273,7 +273,7 @@ def test_split_walk_equals_plain_walk(nb, ctx, n, eps, max_depth):
 # reproducible; ragged sizes, eps = 0 (coincident-body guard), depth-limited and wide leaves (body-by-body path)
 @pytest.mark.parametrize("n,eps,max_depth,leaf_max", [(40000, 0.02, 20, 1), (40001, 0.0, 20, 1), (3000, 0.05, 10, 1),
                                                       (129, 0.05, 20, 1), (20000, 0.02, 3, 1), (20000, 0.01, 20, 8),
-                                                      (20000, 0.0, 4, 1), (300001, 0.02, 20, 1)])
+                                                      (20000, 0.0, 4, 1), (300001, 0.02, 20, 1), (131072, 0.02, 20, 1)])
 def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     ic = nb.ic.two_galaxies(n, seed=23)
     d, _ = to_device(nb, ic)
