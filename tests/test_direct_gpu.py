@@ -409,7 +409,9 @@ def test_deterministic_symmetric_kernel(nb, oracle, ctx, n, tpl, equal_mass):
         ctx.deterministic(False)
         ctx.tuning()
     assert torch.equal(a, b) and torch.equal(a, c)  # bit for bit, launch after launch
-    assert rel_err(a.cpu().numpy()[:, :3], plain.cpu().numpy()[:, :3]).max() < 1e-6
+    # (the two forms may run with different bodies per lane -- general masses: 12 with slots, 16 with atomics --
+    # i.e. other fp32 partial sums; the oracle comparison below is the bar)
+    assert rel_err(a.cpu().numpy()[:, :3], plain.cpu().numpy()[:, :3]).max() < 5e-6
     rng = np.random.default_rng(1)
     idx = np.unique(np.concatenate([rng.choice(n, 768, replace=False), np.arange(n - 200, n), np.arange(200)]))
     ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,

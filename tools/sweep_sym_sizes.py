@@ -22,7 +22,7 @@ def bodies(n, seed):
 for n in (32768, 65536, 131072, 262144, 524288, 1 << 20, 1 << 21):
     p = bodies(n, 42)
     line = f"all-pairs N={n}:"
-    for R in (4, 8, 16):
+    for R in (4, 8, 12, 16):
         ctx.tuning(3, R, 0)
         ms = nb.time_direct_packed(ctx, p, p, 1.0, 1e-6, 3 if n < (1 << 21) else 1)
         line += f"  R={R} {ms:.3f} ms ({float(n) * n / ms / 1e9:.2f}e12/s)"
