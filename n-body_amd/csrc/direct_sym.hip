@@ -367,7 +367,7 @@ static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
   if (two_sets) return n >= 49152 ? 16 : (n >= 16384 ? 8 : 4);
   // (tools/sweep_sym_sizes.py, deterministic slots: 262,144 bodies 10.45 ms at 16 per lane against 10.89 at 8;
   // 131,072: 2.80 ms at 12 -- two workgroups per CU -- against 2.92 at 8)
-  return n >= 200000 ? 16 : (n >= 100000 ? 12 : (n >= 28000 ? 8 : 4));
+  return n >= 200000 ? 16 : (n >= 100000 ? 12 : (n >= 28000 ? 8 : 6));  // (6: tools/sweep_mid.py, 12,288 bodies 0.064 vs 0.076 ms at 4)
 }
 
 namespace {

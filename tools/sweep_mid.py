@@ -13,14 +13,14 @@ import nbody_amd as nb  # noqa: E402
 SPLITS = [int(x) for x in sys.argv[1:]] or [0]
 torch.cuda.set_device(0)
 ctx = nb.default_context(0)
-for n in (8192, 16384, 24576, 32768, 49152, 65536, 98304, 131072):
+for n in (4096, 8192, 10000, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072):
     ic = nb.ic.plummer(n, seed=42)
     p = torch.from_numpy(np.ascontiguousarray(np.stack([ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"]], 1))).cuda()
     line = f"N={n}:"
     ctx.tuning(1, 0, 0)
     ms = nb.time_direct_packed(ctx, p, p, 1.0, 1e-6, 5)
     line += f"  one-sided {ms:.3f} ms ({float(n) * n / ms / 1e9:.2f}e12)"
-    for R in (2, 4, 8):
+    for R in (2, 4, 6, 8):
         for splits in SPLITS:
             ctx.tuning(3, R, splits)
             ms = nb.time_direct_packed(ctx, p, p, 1.0, 1e-6, 5)
