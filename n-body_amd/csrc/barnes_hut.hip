@@ -408,87 +408,119 @@ __global__ __launch_bounds__(kTopBlock) void top_monopole_kernel(int top_level,
 }
 
 // ---------------------------------------------------------------------------------------
-// Monopoles without the level-by-level dependency, for small trees (n <= kPrefixMax): a node covers a
-// contiguous range of the Morton-sorted bodies, so its {sum m, sum m r} is a difference of two
-// entries of the fp64 prefix sums over the sorted bodies.  Two launches instead of eleven dependent
-// passes (57 -> 12 us at 10,000 bodies).  The subtraction loses |prefix| / |node| of fp64's 1e-16:
-// invisible after rounding to the fp32 traversal record; one-body leaves are copied, not subtracted.
-// Deterministic (fixed summation tree).  Large trees keep the bottom-up passes, whose cost is
-// bandwidth, not latency, and whose sums are exact to fp64 at every level.
+// Monopoles without the level-by-level dependency, for trees of up to kPrefixMax bodies: a node covers a
+// contiguous range of the Morton-sorted bodies, so its {sum m, sum m r} is a difference of two entries of the
+// prefix sums over the sorted bodies.  Three launches instead of one per level (17 at the default depth, each a
+// ~5 us floor).  The prefix sums are carried in DOUBLE-DOUBLE (exact products m x by fma, two-sum additions):
+// the subtraction of two long prefixes would otherwise lose |prefix| / |node| of fp64's 1e-16 -- 1e-10 of a
+// two-body node among a quarter of a million, enough to move the fp32 record of one node in a thousand by an
+// ulp -- whereas a double-double difference is exact to ~1e-30 and the monopole is the correctly rounded fp64
+// quotient, as close to the bottom-up fp64 sums (and to the oracle's) as those are to each other.  One-body leaves
+// are copied, not subtracted.  Deterministic (fixed summation tree).  Larger trees keep the bottom-up passes:
+// there the per-level kernels are bandwidth, not launch floor.
 // ---------------------------------------------------------------------------------------
-constexpr int kPrefixMax = 16384;
+constexpr int kPrefixMax = 262144;
 constexpr int kPrefixBlock = 1024;
 
-// pass 1: one body per thread (coalesced), prefix inside each workgroup of kPrefixBlock bodies; P[k] = sums over
-// the workgroup's bodies before k, btot[b] = the workgroup's total.  (One workgroup looping over ten bodies per
-// thread was 29 us at 10,000 bodies: every load and store a 64-way scatter through a single CU.)
-__global__ __launch_bounds__(kPrefixBlock) void prefix_bodies_kernel(const float4* __restrict__ sorted, int n,
-                                                                     double4* __restrict__ P,
-                                                                     double4* __restrict__ btot) {
-  __shared__ double tot[4][2 * (kPrefixBlock / 64)];
-  const int tid = threadIdx.x, k = blockIdx.x * kPrefixBlock + tid;
-  const int lane = tid & 63, wv = tid >> 6;
-  double v[4] = {0.0, 0.0, 0.0, 0.0};
-  if (k < n) {
-    const float4 p = sorted[k];
-    const double mb = (double)p.w;
-    v[0] = mb * (double)p.x; v[1] = mb * (double)p.y; v[2] = mb * (double)p.z; v[3] = mb;
-  }
-  // inclusive scan inside each wave by shuffles, then the 16 wave totals by one wave through LDS (two
-  // barriers; fixed summation tree = deterministic)
-  double inc[4];
+struct dd4 {  // {sum m x, sum m y, sum m z, sum m} as unevaluated sums hi + lo
+  double hi[4], lo[4];
+};
+__device__ __forceinline__ void dd_add(double& ahi, double& alo, double bhi, double blo) {  // a += b
+  const double s = ahi + bhi;
+  const double bb = s - ahi;
+  double e = (ahi - (s - bb)) + (bhi - bb);  // two-sum: s + e = ahi + bhi exactly
+  e += alo + blo;
+  const double hi = s + e;
+  alo = e - (hi - s);  // fast two-sum (|s| >= |e|)
+  ahi = hi;
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int off) { return __shfl_up(v, off, 64); }
+
+// inclusive scan of one dd4 per thread over a workgroup of kPrefixBlock threads (wave scans by shuffles, the wave
+// totals by wave 0 through LDS); returns the EXCLUSIVE prefix of the thread, *total = the workgroup's sum
+__device__ __forceinline__ dd4 block_exclusive_dd(const dd4& v, dd4* total) {
+  constexpr int NW = kPrefixBlock / 64;
+  __shared__ double tot[8][2 * NW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  dd4 inc = v;
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    double x = v[c];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(x, off, 64);
-      if (lane >= off) x += u;
+      const double uh = shfl_up_f64(inc.hi[c], off), ul = shfl_up_f64(inc.lo[c], off);
+      if (lane >= off) dd_add(inc.hi[c], inc.lo[c], uh, ul);
     }
-    inc[c] = x;
-    if (lane == 63) tot[c][wv] = x;
+    if (lane == 63) { tot[c][wv] = inc.hi[c]; tot[4 + c][wv] = inc.lo[c]; }
   }
   __syncthreads();
-  constexpr int NW = kPrefixBlock / 64;
   if (wv == 0) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      double x = lane < NW ? tot[c][lane] : 0.0;
+      double h = lane < NW ? tot[c][lane] : 0.0, l = lane < NW ? tot[4 + c][lane] : 0.0;
 #pragma unroll
       for (int off = 1; off < NW; off <<= 1) {
-        const double u = __shfl_up(x, off, 64);
-        if (lane >= off) x += u;
+        const double uh = shfl_up_f64(h, off), ul = shfl_up_f64(l, off);
+        if (lane >= off) dd_add(h, l, uh, ul);
       }
-      if (lane < NW) tot[c][NW + lane] = x;  // inclusive scan of the wave totals
+      if (lane < NW) { tot[c][NW + lane] = h; tot[4 + c][NW + lane] = l; }  // inclusive scan of the wave totals
     }
   }
   __syncthreads();
-  double ex[4];
+  dd4 ex;
 #pragma unroll
-  for (int c = 0; c < 4; c++) ex[c] = (wv > 0 ? tot[c][NW + wv - 1] : 0.0) + (inc[c] - v[c]);
-  if (k <= n) P[k] = make_double4(ex[0], ex[1], ex[2], ex[3]);  // (P[n] = the last workgroup's sum so far)
-  if (tid == kPrefixBlock - 1)
-    btot[blockIdx.x] = make_double4(tot[0][2 * NW - 1], tot[1][2 * NW - 1], tot[2][2 * NW - 1], tot[3][2 * NW - 1]);
+  for (int c = 0; c < 4; c++) {
+    // exclusive inside the wave = the lane before's inclusive value (exact, no subtraction)
+    const double ph = shfl_up_f64(inc.hi[c], 1), pl = shfl_up_f64(inc.lo[c], 1);
+    ex.hi[c] = lane > 0 ? ph : 0.0;
+    ex.lo[c] = lane > 0 ? pl : 0.0;
+    if (wv > 0) dd_add(ex.hi[c], ex.lo[c], tot[c][NW + wv - 1], tot[4 + c][NW + wv - 1]);
+    total->hi[c] = tot[c][2 * NW - 1];
+    total->lo[c] = tot[4 + c][2 * NW - 1];
+  }
+  return ex;
 }
 
-// pass 2: add the totals of the workgroups before (at most 16, summed in order by every thread)
-__global__ __launch_bounds__(kPrefixBlock) void prefix_offsets_kernel(int n, double4* __restrict__ P,
-                                                                      const double4* __restrict__ btot) {
+// pass 1: one body per thread (coalesced); P[k] = sums over the workgroup's bodies before k, btot[b] = the
+// workgroup's total.  Entry n (the grand total) is thread n's "sum before".
+__global__ __launch_bounds__(kPrefixBlock) void prefix_bodies_kernel(const float4* __restrict__ sorted, int n,
+                                                                     dd4* __restrict__ P, dd4* __restrict__ btot) {
   const int k = blockIdx.x * kPrefixBlock + threadIdx.x;
-  if (blockIdx.x == 0 || k > n) return;
-  double o[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int b = 0; b < (int)blockIdx.x; b++) {
-    const double4 t = btot[b];
-    o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+  dd4 v;
+#pragma unroll
+  for (int c = 0; c < 4; c++) v.hi[c] = v.lo[c] = 0.0;
+  if (k < n) {
+    const float4 p = sorted[k];
+    const double mb = (double)p.w;
+    const double r[3] = {(double)p.x, (double)p.y, (double)p.z};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {  // m x exactly: fp32 x fp32 fits fp64, the fma keeps it honest for any input
+      v.hi[c] = mb * r[c];
+      v.lo[c] = __builtin_fma(mb, r[c], -v.hi[c]);
+    }
+    v.hi[3] = mb;
   }
-  double4 p = P[k];
-  p.x += o[0]; p.y += o[1]; p.z += o[2]; p.w += o[3];
-  P[k] = p;
+  dd4 total;
+  const dd4 ex = block_exclusive_dd(v, &total);
+  if (k <= n) P[k] = ex;
+  if (threadIdx.x == 0) btot[blockIdx.x] = total;
+}
+
+// pass 2 (one workgroup): boff[b] = sum of the totals of the workgroups before b
+__global__ __launch_bounds__(kPrefixBlock) void prefix_blocks_kernel(int nblocks, const dd4* __restrict__ btot,
+                                                                     dd4* __restrict__ boff) {
+  dd4 v;
+#pragma unroll
+  for (int c = 0; c < 4; c++) v.hi[c] = v.lo[c] = 0.0;
+  if ((int)threadIdx.x < nblocks) v = btot[threadIdx.x];
+  dd4 total;
+  const dd4 ex = block_exclusive_dd(v, &total);
+  if ((int)threadIdx.x < nblocks) boff[threadIdx.x] = ex;
 }
 
 __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __restrict__ level_base, int max_depth,
                                                                  const float4* __restrict__ sorted,
-                                                                 const double4* __restrict__ P,
+                                                                 const dd4* __restrict__ P,
+                                                                 const dd4* __restrict__ boff,
                                                                  const TreeRoot* __restrict__ root, TreeArrays t) {
   const int nid = blockIdx.x * kBlock + threadIdx.x;
   if (nid >= level_base[max_depth + 1]) return;
@@ -501,10 +533,19 @@ __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __re
     const float4 p = sorted[first];
     mono = make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
   } else {
-    const double4 a = P[first], b = P[last];
-    const double ms = b.w - a.w;
-    mono = ms > 0.0 ? make_double4((b.x - a.x) / ms, (b.y - a.y) / ms, (b.z - a.z) / ms, ms)
-                    : make_double4(0.0, 0.0, 0.0, 0.0);
+    // (P[last] + boff[its workgroup]) - (P[first] + boff[its workgroup]) in double-double
+    dd4 hi = P[last], lo = P[first];
+    const dd4 oh = boff[last / kPrefixBlock], ol = boff[first / kPrefixBlock];
+    double s[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      dd_add(hi.hi[c], hi.lo[c], oh.hi[c], oh.lo[c]);
+      dd_add(lo.hi[c], lo.lo[c], ol.hi[c], ol.lo[c]);
+      dd_add(hi.hi[c], hi.lo[c], -lo.hi[c], -lo.lo[c]);
+      s[c] = hi.hi[c] + hi.lo[c];
+    }
+    mono = s[3] > 0.0 ? make_double4(s[0] / s[3], s[1] / s[3], s[2] / s[3], s[3])
+                      : make_double4(0.0, 0.0, 0.0, 0.0);
   }
   const float h = ldexpf(root->half, -level);
   const float size = 2.0f * h;  // :168
@@ -1025,7 +1066,8 @@ struct nbody_hip_tree {
   size_t tmp_bytes = 0;
   unsigned long long* d_visits = nullptr;
   double* d_partial = nullptr;  // replicas x 3 x n fp64 partial sums (split traversal)
-  double4* d_prefix = nullptr;  // kPrefixMax + 1 prefix sums of the sorted bodies (small trees) + workgroup totals
+  dd4* d_prefix = nullptr;  // prefix_cap prefix sums of the sorted bodies + workgroup totals + offsets
+  size_t prefix_cap = 0;
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
   int tune_form = 0;                            // walk without replicas: 0 = automatic, 1 = plain, 2 = pair walk
   // cost-ordered schedule of the pair walk (walk_plan_kernel): node visits per wave of the previous walk
@@ -1126,7 +1168,8 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   if (e == hipSuccess) e = dmalloc(&g->d_sorted, n);
   if (e == hipSuccess) e = dmalloc(&g->d_visits, kVisitWords);
   if (e == hipSuccess) e = dmalloc(&g->d_partial, (size_t)3 * kSplitBudget);
-  if (e == hipSuccess) e = dmalloc(&g->d_prefix, (size_t)kPrefixMax + 8 + kPrefixMax / kPrefixBlock + 2);
+  g->prefix_cap = std::min((size_t)kPrefixMax, n) + 8;
+  if (e == hipSuccess) e = dmalloc(&g->d_prefix, g->prefix_cap + 2 * (kPrefixMax / kPrefixBlock + 2));
   {
     const size_t waves = n / 64 + 1, cap = waves / 8 + waves / 32 + 8;
     if (e == hipSuccess) e = dmalloc(&g->d_cost, waves);
@@ -1226,16 +1269,17 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     // small tree: every node's monopole from the prefix sums of the sorted bodies (see above)
     // (ni + 1 entries: entry ni, the total, is thread ni's "sum before")
     const int pblocks = ni / kPrefixBlock + 1;
-    double4* btot = g->d_prefix + kPrefixMax + 8;
+    dd4* btot = g->d_prefix + g->prefix_cap;
+    dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
     hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix,
                        btot);
-    if (pblocks > 1)
-      hipLaunchKernelGGL(prefix_offsets_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, ni, g->d_prefix, btot);
+    hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
     // the node count is only known on the device: one thread per possible node of a tree of ni bodies
     const size_t node_bound = std::min((size_t)g->capacity,
                                        n + (size_t)levels * (n / (size_t)(g->leaf_max + 1) + 1) + 16);
     hipLaunchKernelGGL(prefix_monopole_kernel, dim3((unsigned)((node_bound + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, g->d_level_base, g->max_depth, g->d_sorted, g->d_prefix, g->d_root, g->t);
+                       dim3(kBlock), 0, st, g->d_level_base, g->max_depth, g->d_sorted, g->d_prefix, boff, g->d_root,
+                       g->t);
   } else {
     // monopoles bottom-up: wide levels one launch each, the narrow top in a single workgroup
     const int top = g->max_depth < 4 ? g->max_depth : 4;
