@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kTopBlock) void top_monopole_kernel(int top_level,
 }
 
 // ---------------------------------------------------------------------------------------
-// Monopoles without the level-by-level dependency, for trees of up to kPrefixMax bodies: a node covers a
+// Monopoles without the level-by-level dependency, for trees of up to kPrefixMax (1.5 M) bodies: a node covers a
 // contiguous range of the Morton-sorted bodies, so its {sum m, sum m r} is a difference of two entries of the
 // prefix sums over the sorted bodies.  Three launches instead of one per level (17 at the default depth, each a
 // ~5 us floor).  The prefix sums are carried in DOUBLE-DOUBLE (exact products m x by fma, two-sum additions):
@@ -417,9 +417,13 @@ __global__ __launch_bounds__(kTopBlock) void top_monopole_kernel(int top_level,
 // ulp -- whereas a double-double difference is exact to ~1e-30 and the monopole is the correctly rounded fp64
 // quotient, as close to the bottom-up fp64 sums (and to the oracle's) as those are to each other.  One-body leaves
 // are copied, not subtracted.  Deterministic (fixed summation tree).  Larger trees keep the bottom-up passes:
-// there the per-level kernels are bandwidth, not launch floor.
+// there the per-level kernels are bandwidth, not launch floor (N = 2^20: build 0.54 -> 0.51 ms with the
+// prefixes, N = 2^22: 1.47 -> 1.51 ms).
 // ---------------------------------------------------------------------------------------
-constexpr int kPrefixMax = 262144;
+#ifndef NBH_BH_PREFIX_MAX
+#define NBH_BH_PREFIX_MAX 1572864
+#endif
+constexpr int kPrefixMax = NBH_BH_PREFIX_MAX;
 constexpr int kPrefixBlock = 1024;
 
 struct dd4 {  // {sum m x, sum m y, sum m z, sum m} as unevaluated sums hi + lo
@@ -505,16 +509,28 @@ __global__ __launch_bounds__(kPrefixBlock) void prefix_bodies_kernel(const float
   if (threadIdx.x == 0) btot[blockIdx.x] = total;
 }
 
-// pass 2 (one workgroup): boff[b] = sum of the totals of the workgroups before b
+// pass 2 (one workgroup): boff[b] = sum of the totals of the workgroups before b; a thread takes
+// ceil(nblocks / kPrefixBlock) consecutive workgroups
 __global__ __launch_bounds__(kPrefixBlock) void prefix_blocks_kernel(int nblocks, const dd4* __restrict__ btot,
                                                                      dd4* __restrict__ boff) {
+  const int per = (nblocks + kPrefixBlock - 1) / kPrefixBlock;
+  const int b0 = min(nblocks, (int)threadIdx.x * per), b1 = min(nblocks, b0 + per);
   dd4 v;
 #pragma unroll
   for (int c = 0; c < 4; c++) v.hi[c] = v.lo[c] = 0.0;
-  if ((int)threadIdx.x < nblocks) v = btot[threadIdx.x];
+  for (int b = b0; b < b1; b++) {
+    const dd4 t = btot[b];
+#pragma unroll
+    for (int c = 0; c < 4; c++) dd_add(v.hi[c], v.lo[c], t.hi[c], t.lo[c]);
+  }
   dd4 total;
-  const dd4 ex = block_exclusive_dd(v, &total);
-  if ((int)threadIdx.x < nblocks) boff[threadIdx.x] = ex;
+  dd4 run = block_exclusive_dd(v, &total);
+  for (int b = b0; b < b1; b++) {
+    boff[b] = run;
+    const dd4 t = btot[b];
+#pragma unroll
+    for (int c = 0; c < 4; c++) dd_add(run.hi[c], run.lo[c], t.hi[c], t.lo[c]);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __restrict__ level_base, int max_depth,
