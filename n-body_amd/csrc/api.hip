@@ -186,6 +186,7 @@ extern "C" int nbody_hip_graph_launch(nbody_hip_graph* g, int times) {
     return NBH_FAIL(NBODY_HIP_ERR_STATE, "step graph is stale: device buffers of its context were re-allocated "
                     "after it was recorded (record it again)");
   NBH_HIP(hipSetDevice(g->ctx->device));
+  g->ctx->graph_replays += (unsigned long long)(times > 0 ? times : 0);
   for (int i = 0; i < times; i++) NBH_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
   return NBODY_HIP_OK;
 }

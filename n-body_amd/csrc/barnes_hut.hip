@@ -83,9 +83,9 @@ struct TreeRoot {
   int pad[3];
 };
 
-__global__ void tree_root_kernel(const unsigned int* __restrict__ enc, TreeRoot* __restrict__ root,
-                                 int* __restrict__ level_base) {
-  if (threadIdx.x != 0) return;
+// root cube from the bounding box (enc = order-preserving encodings of {min x, y, z, max x, y, z})
+__device__ __forceinline__ TreeRoot root_from_bbox(const unsigned int* __restrict__ enc) {
+  TreeRoot r;
   float ext = 0.f, c[3];
   for (int a = 0; a < 3; a++) {
     const float lo = ordered_to_float(enc[a]), hi = ordered_to_float(enc[3 + a]);
@@ -93,10 +93,10 @@ __global__ void tree_root_kernel(const unsigned int* __restrict__ enc, TreeRoot*
     ext = fmaxf(ext, hi - lo);
   }
   const float half = ext * 0.5f + 0.001f;  // :343
-  for (int a = 0; a < 3; a++) root->lo[a] = c[a] - half;
-  root->half = half;
-  root->scale = 1024.0f / (2.0f * half);
-  level_base[0] = 0;
+  for (int a = 0; a < 3; a++) r.lo[a] = c[a] - half;
+  r.half = half;
+  r.scale = 1024.0f / (2.0f * half);
+  return r;
 }
 
 __device__ __forceinline__ unsigned int expand_bits10(unsigned int v) {  // :23-29
@@ -139,29 +139,34 @@ template <> struct KeyTraits<unsigned long long> {
   }
 };
 
+// Keys of all bodies; every thread derives the root cube from the bounding box itself (six scalar loads), thread
+// 0 publishes it for the later passes and re-arms the OTHER bounding-box buffer for the next build (two buffers
+// alternate, so the build needs no separate init and no separate root launch).
 template <class K>
 __global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ posm, int n,
-                                                        const TreeRoot* __restrict__ root,
+                                                        const unsigned int* __restrict__ enc,
+                                                        unsigned int* __restrict__ enc_next,
+                                                        TreeRoot* __restrict__ root_out, int* __restrict__ level_base,
                                                         K* __restrict__ keys, int* __restrict__ idx) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  const TreeRoot root = root_from_bbox(enc);
+  if (i == 0) {
+    *root_out = root;
+    level_base[0] = 0;
+    for (int a = 0; a < 3; a++) { enc_next[a] = 0xffffffffu; enc_next[3 + a] = 0u; }  // the empty box
+  }
   if (i >= n) return;
   const float4 p = posm[i];
-  const float s = root->scale * KeyTraits<K>::kRefine;
+  const float s = root.scale * KeyTraits<K>::kRefine;
   const int top = (1 << KeyTraits<K>::kAxisBits) - 1;
-  int qx = (int)((p.x - root->lo[0]) * s);
-  int qy = (int)((p.y - root->lo[1]) * s);
-  int qz = (int)((p.z - root->lo[2]) * s);
+  int qx = (int)((p.x - root.lo[0]) * s);
+  int qy = (int)((p.y - root.lo[1]) * s);
+  int qz = (int)((p.z - root.lo[2]) * s);
   qx = min(max(qx, 0), top); qy = min(max(qy, 0), top); qz = min(max(qz, 0), top);
   keys[i] = KeyTraits<K>::interleave(qx, qy, qz);
   idx[i] = i;
 }
 
-__global__ __launch_bounds__(kBlock) void gather_kernel(const float4* __restrict__ posm,
-                                                        const int* __restrict__ idx, int n,
-                                                        float4* __restrict__ out) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k < n) out[k] = posm[idx[k]];
-}
 
 // 32-byte traversal record: one s_load_dwordx8 per node, eight siblings = 256 contiguous bytes
 struct __attribute__((aligned(32))) NodeRec {
@@ -239,9 +244,13 @@ __device__ __forceinline__ int side_extent(const K* __restrict__ keys, int i, in
 template <class K>
 __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict__ keys,
                                                             int n, int max_depth, int leaf_max,
-                                                            unsigned int* __restrict__ lvlmask) {
+                                                            unsigned int* __restrict__ lvlmask,
+                                                            const float4* __restrict__ posm,
+                                                            const int* __restrict__ sorted_idx,
+                                                            float4* __restrict__ sorted) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  sorted[i] = posm[sorted_idx[i]];  // the bodies in Morton order (the gather rides along: one launch less)
   const K k = keys[i];
   // first body of its group at level L  <=>  (d >> (top - 3L)) != 0; body 0 heads every level
   const K d = i == 0 ? ~(K)0 : (k ^ keys[i - 1]);
@@ -1069,7 +1078,10 @@ struct nbody_hip_tree {
   int max_depth = kDefaultDepth;
   int leaf_max = 1;
   int capacity = 0;
-  unsigned int* d_enc = nullptr;
+  unsigned int* d_enc = nullptr;  // two bounding-box buffers of 8 words (see morton_kernel)
+  unsigned int enc_flip = 0;
+  bool enc_armed = false;
+  unsigned long long enc_replays = 0;
   TreeRoot* d_root = nullptr;
   int* d_level_base = nullptr;  // kMaxDepth + 3 ints
   void *d_keys_a = nullptr, *d_keys_b = nullptr;  // 32-bit keys up to depth 10, 64-bit keys beyond
@@ -1176,7 +1188,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   g->ctx = ctx;
   g->max_particles = max_particles;
   const size_t n = max_particles;
-  hipError_t e = dmalloc(&g->d_enc, 8);
+  hipError_t e = dmalloc(&g->d_enc, 16);
   if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_a, n);
@@ -1242,26 +1254,35 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
 
+  // two bounding-box buffers alternate: this build's was re-armed by the previous build's morton_kernel
+  unsigned int* enc = g->d_enc + 8 * (g->enc_flip & 1);
+  unsigned int* enc_next = g->d_enc + 8 * ((g->enc_flip + 1) & 1);
+  g->enc_flip++;
+  // armed: false on the first build and after a build that failed half way.  A recorded step graph replays this
+  // very launch sequence on the SAME buffer every time, so while capturing (and right after) the init stays in.
+  const bool armed = g->enc_armed && !ctx->capturing && g->enc_replays == ctx->graph_replays;
+  g->enc_armed = false;
   if (soa) {
-    if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, g->d_enc)) return rc;
+    if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, enc, !armed)) return rc;
   } else {
-    if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+    if (int rc = launch_bbox(ctx, posm, ni, enc, !armed)) return rc;
   }
-  hipLaunchKernelGGL(tree_root_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->d_root, g->d_level_base);
   // topology of every level: keys, sort, flags, one scan, fill (see tree_flags_kernel)
   const int levels = g->max_depth + 1;
   const size_t total = (size_t)levels * n;
   auto topology = [&](auto* ka, auto* kb, int first_bit, int key_bits) -> int {
     using K = std::remove_pointer_t<decltype(ka)>;
-    hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_root, ka, g->d_idx_a);
+    hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, enc, enc_next, g->d_root,
+                       g->d_level_base, ka, g->d_idx_a);
     NBH_LAUNCH_CHECK();
+    g->enc_armed = !ctx->capturing;
+    g->enc_replays = ctx->graph_replays;
     size_t tmp = g->tmp_bytes;
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
     NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
     unsigned int* lvlmask = reinterpret_cast<unsigned int*>(g->d_idx_a);  // idx_a is free after the sort
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       lvlmask);
+                       lvlmask, posm, g->d_idx_b, g->d_sorted);
     NBH_LAUNCH_CHECK();
     tmp = g->tmp_bytes;
     NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, level_flags(lvlmask, (unsigned int)ni), g->d_incl, total,

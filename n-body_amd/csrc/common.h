@@ -82,6 +82,9 @@ struct nbody_hip_ctx {
   // bumped when a tree / grid of this context re-sizes or frees device arrays a recorded step graph
   // may point into; together with the workspaces' generations it dates a recording
   unsigned long long alloc_generation = 0;
+  // replays of recorded step graphs so far: a replay runs launches this library did not see, so state the host
+  // side assumes about device buffers between calls (a tree's re-armed bounding box) is dated with it
+  unsigned long long graph_replays = 0;
   unsigned long long generation() const {
     return posm.generation + partial.generation + reduce.generation + alloc_generation;
   }
@@ -117,9 +120,10 @@ int pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z
 
 // spatial_hash.hip: order-preserving-integer bounding box of packed bodies into enc[6]
 // (min x,y,z then max x,y,z); decode with ordered_to_float on the device.
-int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc);
+int launch_bbox_init(nbody_hip_ctx* ctx, unsigned int* enc);
+int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc, bool init = true);
 int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
-                     float4* posm, unsigned int* enc);
+                     float4* posm, unsigned int* enc, bool init = true);
 
 __device__ __forceinline__ unsigned int float_to_ordered(float f) {
   const unsigned int u = __float_as_uint(f);

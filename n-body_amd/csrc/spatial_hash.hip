@@ -117,19 +117,26 @@ __global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restri
   block_bbox_commit(lo, hi, red, enc);
 }
 
-int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
-                     float4* posm, unsigned int* enc) {
-  const int blocks = (n + kBlock - 1) / kBlock;
+int launch_bbox_init(nbody_hip_ctx* ctx, unsigned int* enc) {
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+// init = false: enc already holds the empty box (the caller re-armed it, see tree_build_packed)
+int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
+                     float4* posm, unsigned int* enc, bool init) {
+  const int blocks = (n + kBlock - 1) / kBlock;
+  if (init) hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
   hipLaunchKernelGGL(pack_bbox_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream, x, y, z, m,
                      n, posm, enc);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
 
-int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc) {
+int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc, bool init) {
   const int blocks = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
+  if (init) hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
   hipLaunchKernelGGL(bbox_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream,
                      posm, n, enc);
   NBH_LAUNCH_CHECK();
