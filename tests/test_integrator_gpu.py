@@ -202,6 +202,30 @@ def test_step_graph_replays_eager_steps(nb, ctx, method, n):
     assert np.array_equal(out[0], out[1])
 
 
+# eager steps, replays and eager steps again on the same tree: the Barnes-Hut build keeps host-side state about
+# its device buffers between calls (the re-armed bounding box), which a replay must invalidate
+@pytest.mark.parametrize("n", [3000, 120000])
+def test_step_graph_mixed_with_eager_steps(nb, ctx, n):
+    ic = nb.ic.two_galaxies(n, seed=12)
+    out = []
+    for mixed in (False, True):
+        d, _ = to_device(nb, ic)
+        fc = nb.BarnesHutCalculator(0.5)
+        fc.setSofteningParameter(0.05)
+        integ = nb.Integrator()
+        fc.computeForces(d)
+        if mixed:
+            integ.integrate_steps(d, fc, 1e-3, 2, graph=False)
+            integ.integrate_steps(d, fc, 1e-3, 3, graph=True)
+            integ.integrate_steps(d, fc, 1e-3, 2, graph=False)
+            integ.integrate_steps(d, fc, 1e-3, 1, graph=True)
+            integ.integrate_steps(d, fc, 1e-3, 1, graph=False)
+        else:
+            integ.integrate_steps(d, fc, 1e-3, 9, graph=False)
+        out.append(np.stack([d.pos_x.cpu().numpy(), d.vel_y.cpu().numpy(), d.acc_z.cpu().numpy()]))
+    assert np.array_equal(out[0], out[1])
+
+
 def test_step_graph_rejects_host_round_trips(nb, ctx):
     ic = nb.ic.uniform_box(2000, seed=3, lo=-4.0, hi=4.0)
     d, _ = to_device(nb, ic)
