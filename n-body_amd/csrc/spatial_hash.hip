@@ -165,20 +165,29 @@ __host__ __device__ inline long long grid_cells_times(long long total, int d) {
 }
 
 // decode, pad by `pad` (0.001 for the hash grid, force_spatial_hash.cu:225-231), size the grid
+// host_info: the same record in pinned host memory (mapped into the device's address space): the build's one host
+// round trip then needs only the stream synchronisation, not a device-to-host copy on top (a 40-byte
+// hipMemcpyAsync ran as a 27 us copy kernel)
 __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cell, float pad,
-                                 GridInfo* __restrict__ info) {
+                                 GridInfo* __restrict__ info, GridInfo* __restrict__ host_info) {
   if (threadIdx.x != 0) return;
+  GridInfo gi;
   long long total = 1;
   for (int a = 0; a < 3; a++) {
     const float lo = ordered_to_float(enc[a]) - pad;
     const float hi = ordered_to_float(enc[3 + a]) + pad;
-    info->bmin[a] = lo;
-    info->bmax[a] = hi;
+    gi.bmin[a] = lo;
+    gi.bmax[a] = hi;
     const int d = grid_axis_cells(lo, hi, cell);
-    info->dims[a] = d;
+    gi.dims[a] = d;
     total = grid_cells_times(total, d);
   }
-  info->total = total;
+  gi.total = total;
+  *info = gi;
+  if (host_info) {
+    *host_info = gi;
+    __threadfence_system();
+  }
 }
 
 __device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim) {
@@ -698,6 +707,7 @@ struct nbody_hip_grid {
   unsigned int* d_enc = nullptr;       // 6 ordered-int bbox words
   GridInfo* d_info = nullptr;
   GridInfo* h_info = nullptr;          // pinned
+  GridInfo* h_info_dev = nullptr;      // the device's address of h_info (null: not mapped, copy instead)
   unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
@@ -743,7 +753,11 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   const size_t n = max_particles;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_enc), 8 * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_info), sizeof(GridInfo));
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_info), sizeof(GridInfo), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_info), sizeof(GridInfo), hipHostMallocMapped);
+  if (e == hipSuccess && hipHostGetDevicePointer(reinterpret_cast<void**>(&g->h_info_dev), g->h_info, 0) != hipSuccess) {
+    g->h_info_dev = nullptr;
+    (void)hipGetLastError();
+  }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_keys_a), n * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_keys_b), n * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_idx_a), n * sizeof(int));
@@ -828,11 +842,12 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     } else {
       if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
     }
-    hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info);
+    hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info,
+                       g->h_info_dev);
     NBH_LAUNCH_CHECK();
     // the one host round trip of the build: the grid size decides validity (and, for the
     // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
-    NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
+    if (!g->h_info_dev) NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
     NBH_HIP(hipStreamSynchronize(st));
     g->info = *g->h_info;
     if (g->info.total > 100000000LL)  // :252-254
