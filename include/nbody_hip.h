@@ -230,6 +230,9 @@ NBODY_HIP_API int nbody_hip_grid_tuning(nbody_hip_grid* grid, int kernel);
  * NBODY_HIP_ERR_RESOURCE ("Spatial hash grid too large", :252-254).  One host round trip
  * (the grid size), like the reference. */
 NBODY_HIP_API int nbody_hip_grid_build(nbody_hip_grid* grid, const nbody_particle_data* d);
+/* nbody_hip_drift + nbody_hip_grid_build in one pass over the bodies (see nbody_hip_tree_drift_build); used by
+ * Integrator::integrate for exactly the engine's own SpatialHashCalculator. */
+NBODY_HIP_API int nbody_hip_grid_drift_build(nbody_hip_grid* grid, nbody_particle_data* d, float dt);
 /* ref: SpatialHashGrid::computeForces(d_particles, cutoff, G, eps) :305-316 -- takes eps and
  * cutoff unsquared like the reference; OVERWRITES acc_*. */
 NBODY_HIP_API int nbody_hip_grid_compute_forces(nbody_hip_grid* grid, nbody_particle_data* d,
@@ -346,6 +349,12 @@ NBODY_HIP_API int nbody_hip_tree_set_params(nbody_hip_tree* tree, int max_depth,
 /* ref: BarnesHutTree::build :282-289 -- bounding box, Morton keys, sort, octree, monopoles; all on
  * the device, no host round trip (the reference crosses PCIe >= 17 times here). */
 NBODY_HIP_API int nbody_hip_tree_build(nbody_hip_tree* tree, const nbody_particle_data* d);
+/* The drift of a Velocity-Verlet step (ref: Integrator::integrate, integrator.cu:224-238 -- storeOldAccelerations +
+ * updatePositions: a_old <- a ; x += v dt + a dt^2/2) fused with the build that follows it: the positions are
+ * advanced, packed and bounded in ONE pass over the bodies, then the tree is built on them.  Same arithmetic and
+ * results as nbody_hip_drift followed by nbody_hip_tree_build.  Used by Integrator::integrate for exactly the
+ * engine's own BarnesHutCalculator (a subclass goes through its virtual computeForces). */
+NBODY_HIP_API int nbody_hip_tree_drift_build(nbody_hip_tree* tree, nbody_particle_data* d, float dt);
 /* ref: BarnesHutTree::computeForces(d_particles, theta, G, eps) :488-498 -- OVERWRITES acc_*. */
 NBODY_HIP_API int nbody_hip_tree_compute_forces(nbody_hip_tree* tree, nbody_particle_data* d,
                                                 float theta, float G, float eps);

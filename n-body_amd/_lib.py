@@ -93,6 +93,7 @@ PROTOTYPES = {
     "nbody_hip_grid_set_cell_size": (C.c_int, [_P, C.c_float]),
     "nbody_hip_grid_tuning": (C.c_int, [_P, C.c_int]),
     "nbody_hip_grid_build": (C.c_int, [_P, _PD]),
+    "nbody_hip_grid_drift_build": (C.c_int, [_P, _PD, C.c_float]),
     "nbody_hip_grid_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
     "nbody_hip_grid_info": (C.c_int, [_P, C.POINTER(C.c_int * 3), C.POINTER(C.c_int),
                                       C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
@@ -117,6 +118,7 @@ PROTOTYPES = {
     "nbody_hip_tree_visit_histogram": (C.c_int, [_P, C.POINTER(C.c_ulonglong * 130)]),
     "nbody_hip_tree_count_visits": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_build": (C.c_int, [_P, _PD]),
+    "nbody_hip_tree_drift_build": (C.c_int, [_P, _PD, C.c_float]),
     "nbody_hip_tree_compute_forces": (C.c_int, [_P, _PD, C.c_float, C.c_float, C.c_float]),
     "nbody_hip_tree_build_packed": (C.c_int, [_P, _P, C.c_size_t]),
     "nbody_hip_tree_compute_forces_packed": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_float, _P]),

@@ -500,6 +500,12 @@ class SpatialHashGrid:
         self._last_count = d_particles.count
         check(self.ctx._lib.nbody_hip_grid_build(self._h, C.byref(s)))
 
+    def driftBuild(self, d_particles: ParticleData, dt: float):
+        """The drift of a Velocity-Verlet step and this build in one pass (nbody_hip_grid_drift_build)."""
+        s = d_particles.struct()
+        self._last_count = d_particles.count
+        check(self.ctx._lib.nbody_hip_grid_drift_build(self._h, C.byref(s), dt))
+
     def computeForces(self, d_particles: ParticleData, cutoff: float, G: float, eps: float):
         s = d_particles.struct()
         check(self.ctx._lib.nbody_hip_grid_compute_forces(self._h, C.byref(s), cutoff, G, eps))
@@ -648,6 +654,12 @@ class BarnesHutTree:
         check(self.ctx._lib.nbody_hip_tree_build(self._h, C.byref(s)))
         self._count = d_particles.count
 
+    def driftBuild(self, d_particles: ParticleData, dt: float):
+        """The drift of a Velocity-Verlet step and this build in one pass (nbody_hip_tree_drift_build)."""
+        s = d_particles.struct()
+        check(self.ctx._lib.nbody_hip_tree_drift_build(self._h, C.byref(s), dt))
+        self._count = d_particles.count
+
     def computeForces(self, d_particles: ParticleData, theta: float, G: float, eps: float):
         s = d_particles.struct()
         check(self.ctx._lib.nbody_hip_tree_compute_forces(self._h, C.byref(s), theta, G, eps))
@@ -767,6 +779,19 @@ class Integrator:
             fctx = force_calc.ctx
             check(fctx._lib.nbody_hip_integrate_direct(
                 fctx.handle, C.byref(s), force_calc.G_, force_calc.softening_eps2_, dt, 1))
+            return
+        # exactly the engine's own tree / grid calculators (same rule): the drift rides on the packing pass of
+        # their build (one pass over the bodies less); same arithmetic, same results
+        if type(force_calc) is BarnesHutCalculator and force_calc.tree_ is not None:
+            force_calc.tree_.driftBuild(d_particles, dt)
+            force_calc.tree_.computeForces(d_particles, force_calc.theta_, force_calc.G_, force_calc.softening_eps_)
+            self.updateVelocities(d_particles, dt)
+            return
+        if type(force_calc) is SpatialHashCalculator and force_calc.grid_ is not None:
+            force_calc.grid_.driftBuild(d_particles, dt)
+            force_calc.grid_.computeForces(d_particles, force_calc.cutoff_radius_, force_calc.G_,
+                                           force_calc.softening_eps_)
+            self.updateVelocities(d_particles, dt)
             return
         s = d_particles.struct()  # a_old <- a and the position update in one pass
         check(self.ctx._lib.nbody_hip_drift(self.ctx.handle, C.byref(s), dt))

@@ -1248,7 +1248,9 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
 
 // the build proper, from packed bodies
 // soa != nullptr: posm is a scratch array to be filled from the SoA bodies (fused with the bounding box)
-static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nbody_particle_data* soa = nullptr) {
+// drift_dt: soa is a step's state BEFORE its drift; the drift rides on the packing pass (nbody_hip_tree_drift_build)
+static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nbody_particle_data* soa = nullptr,
+                             const float* drift_dt = nullptr) {
   nbody_hip_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
@@ -1262,7 +1264,9 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   // very launch sequence on the SAME buffer every time, so while capturing (and right after) the init stays in.
   const bool armed = g->enc_armed && !ctx->capturing && g->enc_replays == ctx->graph_replays;
   g->enc_armed = false;
-  if (soa) {
+  if (soa && drift_dt) {
+    if (int rc = launch_drift_pack_bbox(ctx, const_cast<nbody_particle_data*>(soa), *drift_dt, posm, enc, !armed)) return rc;
+  } else if (soa) {
     if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, enc, !armed)) return rc;
   } else {
     if (int rc = launch_bbox(ctx, posm, ni, enc, !armed)) return rc;
@@ -1346,6 +1350,24 @@ extern "C" int nbody_hip_tree_build(nbody_hip_tree* g, const nbody_particle_data
   if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
   float4* posm = static_cast<float4*>(ctx->posm.ptr);
   return tree_build_packed(g, posm, n, d);
+}
+
+extern "C" int nbody_hip_tree_drift_build(nbody_hip_tree* g, nbody_particle_data* d, float dt) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  const size_t n = d->count;
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the tree's capacity %zu "
+                    "(sized from the first count seen, ref: force_barnes_hut.cu:527-529)", n, g->max_particles);
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass || !d->vel_x || !d->vel_y || !d->vel_z || !d->acc_x || !d->acc_y ||
+      !d->acc_z || !d->acc_old_x || !d->acc_old_y || !d->acc_old_z)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  return tree_build_packed(g, posm, n, d, &dt);
 }
 
 extern "C" int nbody_hip_tree_build_packed(nbody_hip_tree* g, const nbody_float4* posm, size_t n) {

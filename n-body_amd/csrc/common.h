@@ -25,6 +25,15 @@ constexpr int kNumCU = 256;   // MI355X
 // merge sort wins at 262,144 keys (0.24 vs 0.26 ms tree build), Onesweep from 524,288 (0.14 vs 0.18 ms)
 constexpr size_t kSortMergeLimit = NBH_SORT_MERGE_LIMIT;
 
+#ifdef __HIPCC__
+// x + v dt + a (dt^2 / 2) as p + fma(a, h, v * dt): the contraction nvcc's default -fmad makes of
+// integrator.cu:16-19 -- one definition, so that the SoA, fused and float4 drift kernels round identically
+// (a sharded run then reproduces the single-GPU one bit for bit).
+__device__ __forceinline__ float drift1(float p, float v, float a, float dt, float h) {
+  return p + __builtin_fmaf(a, h, v * dt);
+}
+#endif
+
 void set_error(const char* fmt, ...);
 int fail(nbody_hip_status code, const char* file, int line, const char* fmt, ...);
 
@@ -121,6 +130,10 @@ int pack_posm(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z
 // spatial_hash.hip: order-preserving-integer bounding box of packed bodies into enc[6]
 // (min x,y,z then max x,y,z); decode with ordered_to_float on the device.
 int launch_bbox_init(nbody_hip_ctx* ctx, unsigned int* enc);
+// drift of a Velocity-Verlet step fused with the packing and the bounding box of the following build:
+// a_old <- a ; x += v dt + a dt^2/2 ; posm <- {x, y, z, m} ; enc <- box   (nbody_hip_{tree,grid}_drift_build)
+int launch_drift_pack_bbox(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt, float4* posm, unsigned int* enc,
+                           bool init = true);
 int launch_bbox(nbody_hip_ctx* ctx, const float4* posm, int n, unsigned int* enc, bool init = true);
 int launch_pack_bbox(nbody_hip_ctx* ctx, const float* x, const float* y, const float* z, const float* m, int n,
                      float4* posm, unsigned int* enc, bool init = true);

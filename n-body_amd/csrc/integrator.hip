@@ -27,12 +27,7 @@ static inline int stream_blocks(size_t items) {
 struct Soa3 { float* x; float* y; float* z; };
 struct CSoa3 { const float* x; const float* y; const float* z; };
 
-// x + (v dt + a dt^2/2), written out as ONE explicit chain -- v*dt, then fma(a, h, .), then the add: the
-// contraction nvcc's default -fmad makes of integrator.cu:16-19 -- so that the SoA, fused and float4
-// drift kernels round identically (a sharded run then reproduces the single-GPU one bit for bit).
-__device__ __forceinline__ float drift1(float p, float v, float a, float dt, float h) {
-  return p + __builtin_fmaf(a, h, v * dt);
-}
+// (drift1: common.h)
 
 // x += v*dt + a*(0.5*dt*dt)     (integrator.cu:16-19; same operation order)
 template <int VEC>

@@ -117,6 +117,45 @@ __global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restri
   block_bbox_commit(lo, hi, red, enc);
 }
 
+// the same pass with the drift of the step in front: a_old <- a ; x += v dt + a dt^2/2 (integrator.cu:44-46,
+// :16-19, arithmetic of drift_pack_kernel) ; posm <- {x, y, z, m} ; running min / max of the NEW positions
+__global__ __launch_bounds__(kBlock) void drift_pack_bbox_kernel(float* __restrict__ x, float* __restrict__ y,
+                                                                 float* __restrict__ z, const float* __restrict__ vx,
+                                                                 const float* __restrict__ vy, const float* __restrict__ vz,
+                                                                 const float* __restrict__ ax, const float* __restrict__ ay,
+                                                                 const float* __restrict__ az, float* __restrict__ aox,
+                                                                 float* __restrict__ aoy, float* __restrict__ aoz,
+                                                                 const float* __restrict__ m, int n, float dt,
+                                                                 float4* __restrict__ posm, unsigned int* __restrict__ enc) {
+  __shared__ float red[4][6];
+  const float dt2_half = 0.5f * dt * dt;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float a0 = ax[i], a1 = ay[i], a2 = az[i];
+    aox[i] = a0; aoy[i] = a1; aoz[i] = a2;
+    const float4 p = make_float4(drift1(x[i], vx[i], a0, dt, dt2_half), drift1(y[i], vy[i], a1, dt, dt2_half),
+                                 drift1(z[i], vz[i], a2, dt, dt2_half), m[i]);
+    x[i] = p.x; y[i] = p.y; z[i] = p.z;
+    posm[i] = p;
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+  block_bbox_commit(lo, hi, red, enc);
+}
+
+int launch_drift_pack_bbox(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt, float4* posm, unsigned int* enc,
+                           bool init) {
+  const int n = (int)d->count;
+  const int blocks = (n + kBlock - 1) / kBlock;
+  if (init) hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
+  hipLaunchKernelGGL(drift_pack_bbox_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream, d->pos_x,
+                     d->pos_y, d->pos_z, d->vel_x, d->vel_y, d->vel_z, d->acc_x, d->acc_y, d->acc_z, d->acc_old_x,
+                     d->acc_old_y, d->acc_old_z, d->mass, n, dt, posm, enc);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
 int launch_bbox_init(nbody_hip_ctx* ctx, unsigned int* enc) {
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
   NBH_LAUNCH_CHECK();
@@ -813,8 +852,9 @@ static int bits_for(long long total) {
 // otherwise {lo x,y,z, hi x,y,z} is used as the (already padded) box -- the sharded path passes
 // the GLOBAL box so that every rank bins on the same grid.
 // soa != nullptr: posm is a scratch array to be filled from the SoA bodies (fused with the bounding box)
+// drift_dt: soa is a step's state BEFORE its drift; the drift rides on the packing pass (nbody_hip_grid_drift_build)
 static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const float* bounds,
-                             const nbody_particle_data* soa = nullptr, bool slab = false) {
+                             const nbody_particle_data* soa = nullptr, bool slab = false, const float* drift_dt = nullptr) {
   nbody_hip_ctx* ctx = g->ctx;
   // the grid dimensions come back to the host every build (they size the force launch)
   NBH_NOT_CAPTURABLE(ctx, "the spatial-hash grid build");
@@ -837,7 +877,9 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
     NBH_HIP(hipMemcpyAsync(g->d_info, g->h_info, sizeof(GridInfo), hipMemcpyHostToDevice, st));
   } else {
-    if (soa) {
+    if (soa && drift_dt) {
+      if (int rc = launch_drift_pack_bbox(ctx, const_cast<nbody_particle_data*>(soa), *drift_dt, posm, g->d_enc)) return rc;
+    } else if (soa) {
       if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, g->d_enc)) return rc;
     } else {
       if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
@@ -912,6 +954,24 @@ extern "C" int nbody_hip_grid_build(nbody_hip_grid* g, const nbody_particle_data
   if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
   float4* posm = static_cast<float4*>(ctx->posm.ptr);
   return grid_build_packed(g, posm, n, nullptr, d);
+}
+
+extern "C" int nbody_hip_grid_drift_build(nbody_hip_grid* g, nbody_particle_data* d, float dt) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
+  const size_t n = d->count;
+  if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
+  if (n > g->max_particles)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu exceeds the grid's capacity %zu "
+                    "(sized from the first count seen, ref: force_spatial_hash.cu:372-374)", n, g->max_particles);
+  if (!d->pos_x || !d->pos_y || !d->pos_z || !d->mass || !d->vel_x || !d->vel_y || !d->vel_z || !d->acc_x || !d->acc_y ||
+      !d->acc_z || !d->acc_old_x || !d->acc_old_y || !d->acc_old_z)
+    return NBH_FAIL(NBODY_HIP_ERR_STATE, "particle data has null arrays");
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  if (int rc = ctx->posm.reserve(n * sizeof(float4))) return rc;
+  float4* posm = static_cast<float4*>(ctx->posm.ptr);
+  return grid_build_packed(g, posm, n, nullptr, d, false, &dt);
 }
 
 extern "C" int nbody_hip_grid_build_packed(nbody_hip_grid* g, const nbody_float4* posm, size_t n,

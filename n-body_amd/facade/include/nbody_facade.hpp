@@ -132,6 +132,9 @@ public:
   BarnesHutTree(size_t max_particles);
   ~BarnesHutTree();
   void build(const ParticleData* d_particles);
+  // (facade only, no data member: the drift of a Velocity-Verlet step + build in one pass over the bodies,
+  // nbody_hip_tree_drift_build; Integrator::integrate uses it for exactly the engine's own calculator)
+  void driftBuild(ParticleData* d_particles, float dt);
   void computeForces(ParticleData* d_particles, float theta, float G, float eps);
   int getNodeCount() const { return node_count_; }
   int getMaxDepth() const { return max_depth_; }
@@ -162,6 +165,7 @@ public:
   SpatialHashGrid(size_t max_particles, float cell_size = 1.0f);
   ~SpatialHashGrid();
   void build(const ParticleData* d_particles);
+  void driftBuild(ParticleData* d_particles, float dt);  // facade only, see BarnesHutTree::driftBuild
   void computeForces(ParticleData* d_particles, float cutoff, float G, float eps);
   int3 getGridDims() const { return grid_dims_; }
   float getCellSize() const { return cell_size_; }

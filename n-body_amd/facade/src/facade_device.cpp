@@ -173,6 +173,14 @@ BarnesHutTree::BarnesHutTree(size_t max_particles) : max_particles_(max_particle
   d_nodes_ = reinterpret_cast<OctreeNode*>(t);
 }
 BarnesHutTree::~BarnesHutTree() { nbody_hip_tree_destroy(handle()); }
+void BarnesHutTree::driftBuild(ParticleData* d, float dt) {
+  NBODY_CHECK(nbody_hip_tree_drift_build(handle(), raw(d), dt));
+  int level_base[12];
+  NBODY_CHECK(nbody_hip_tree_stats(handle(), &node_count_, nullptr, nullptr, level_base));
+  max_nodes_ = static_cast<size_t>(node_count_);
+  max_depth_ = 0;
+  for (int l = 1; l < 12; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
+}
 void BarnesHutTree::build(const ParticleData* d) {
   NBODY_CHECK(nbody_hip_tree_build(handle(), raw(d)));
   int level_base[12];
@@ -212,6 +220,15 @@ SpatialHashGrid::SpatialHashGrid(size_t max_particles, float cell_size)
   d_cell_start_ = reinterpret_cast<int*>(g);
 }
 SpatialHashGrid::~SpatialHashGrid() { nbody_hip_grid_destroy(handle()); }
+void SpatialHashGrid::driftBuild(ParticleData* d, float dt) {
+  NBODY_CHECK(nbody_hip_grid_drift_build(handle(), raw(d), dt));
+  int dims[3];
+  float lo[3], hi[3];
+  NBODY_CHECK(nbody_hip_grid_info(handle(), dims, &total_cells_, lo, hi));
+  grid_dims_ = make_int3(dims[0], dims[1], dims[2]);
+  bbox_min_ = Vec3(lo[0], lo[1], lo[2]);
+  bbox_max_ = Vec3(hi[0], hi[1], hi[2]);
+}
 void SpatialHashGrid::build(const ParticleData* d) {
   NBODY_CHECK(nbody_hip_grid_build(handle(), raw(d)));
   int dims[3];
@@ -321,6 +338,26 @@ void Integrator::integrate(ParticleData* d, ForceCalculator* fc, float dt) {
     if (bs >= 1 && bs <= 1024) {
       const float eps = fc->getSofteningParameter();
       NBODY_CHECK(nbody_hip_integrate_direct(facadeContext(), raw(d), fc->getGravitationalConstant(), eps * eps, dt, 1));
+      return;
+    }
+  }
+  // the same rule for the engine's own tree / grid calculators: the drift rides on the packing pass of their
+  // build (one pass over the bodies less; same arithmetic, same results); the first step creates the tree / grid
+  // through computeForces as ever
+  if (typeid(*fc) == typeid(BarnesHutCalculator)) {
+    auto* bc = static_cast<BarnesHutCalculator*>(fc);
+    if (BarnesHutTree* tree = bc->getTree()) {
+      tree->driftBuild(d, dt);
+      tree->computeForces(d, bc->getTheta(), bc->getGravitationalConstant(), bc->getSofteningParameter());
+      updateVelocities(d, dt);
+      return;
+    }
+  } else if (typeid(*fc) == typeid(SpatialHashCalculator)) {
+    auto* sc = static_cast<SpatialHashCalculator*>(fc);
+    if (SpatialHashGrid* grid = sc->getGrid()) {
+      grid->driftBuild(d, dt);
+      grid->computeForces(d, sc->getCutoffRadius(), sc->getGravitationalConstant(), sc->getSofteningParameter());
+      updateVelocities(d, dt);
       return;
     }
   }

@@ -330,6 +330,39 @@ def test_integrate_calls_a_subclass_override(nb, ctx):
         nb.Integrator().integrate(d, bad, 1e-3)
 
 
+# ... and the same for the tree / grid calculators, whose drift rides on the build's packing pass when the
+# calculator is exactly the engine's own: a subclass is called through its override, with the same trajectory
+@pytest.mark.parametrize("method", ["bh", "hash"])
+def test_integrate_fused_drift_build_equals_generic_path(nb, ctx, method):
+    ic = nb.ic.uniform_box(6000, seed=2, lo=-4.0, hi=4.0) if method == "hash" else nb.ic.plummer(6000, seed=2)
+    base = nb.BarnesHutCalculator if method == "bh" else nb.SpatialHashCalculator
+
+    class Counting(base):
+        calls = 0
+
+        def computeForces(self, d_particles):
+            Counting.calls += 1
+            super().computeForces(d_particles)
+
+    def run(fc):
+        d, _ = to_device(nb, ic)
+        fc.setGravitationalConstant(1.0)
+        fc.setSofteningParameter(0.05)
+        fc.computeForces(d)
+        integ = nb.Integrator()
+        for _ in range(4):
+            integ.integrate(d, fc, 1e-3)
+        return _state(d)
+
+    make = (lambda c: c(0.5)) if method == "bh" else (lambda c: c(1.0, 1.0))
+    fused = run(make(base))
+    Counting.calls = 0
+    generic = run(make(Counting))
+    assert Counting.calls == 1 + 4
+    for k in ("pos_x", "pos_z", "vel_y", "acc_z", "acc_old_x"):
+        assert np.array_equal(fused[k], generic[k]), k
+
+
 # A recorded step graph holds raw pointers into the context's workspaces (shared by every system on
 # the device) and into its tree.  When a LARGER system later grows a workspace, or the tree is re-sized,
 # the old buffers are freed: replaying must be refused (NBODY_HIP_ERR_STATE), not touch freed memory;
