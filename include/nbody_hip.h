@@ -370,9 +370,12 @@ NBODY_HIP_API int nbody_hip_tree_compute_forces_packed(nbody_hip_tree* tree, siz
                                                        float theta, float G, float eps, nbody_float4* acc_out);
 /* ref: getNodeCount (barnes_hut_tree.hpp:41) and the root mass used by verifyMassConservation
  * (:511-519); plus node visits (per wave) of the last traversal and the first node id of every
- * level (12 ints).  Any output may be NULL.  Blocking. */
+ * level: level_base[l] for l = 0 .. max_depth + 1 (the last one = node count), repeated up to
+ * NBODY_HIP_TREE_LEVELS entries (trees go down to depth 21; the deepest level that holds nodes is what
+ * the reference's getMaxDepth reports).  Any output may be NULL.  Blocking. */
+#define NBODY_HIP_TREE_LEVELS 24
 NBODY_HIP_API int nbody_hip_tree_stats(nbody_hip_tree* tree, int* node_count, float* root_mass,
-                                       unsigned long long* nodes_visited, int level_base[12]);
+                                       unsigned long long* nodes_visited, int level_base[NBODY_HIP_TREE_LEVELS]);
 /* ref: copyNodesToHost / getNodes :500-503 -- writes the tree into HOST memory in the reference's
  * OctreeNode layout (76 bytes, barnes_hut_tree.hpp:9-30), children indexed by octant; optionally
  * the Morton order (sorted position -> body index, `count` ints).  Blocking. */
@@ -389,17 +392,48 @@ NBODY_HIP_API int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_f
                                  nbody_float4* acc_out, float G, float eps2, int iters,
                                  float* ms_per_launch);
 
-/* Direct forces are bitwise reproducible at every size, like the reference's one-thread-per-body loop
- * (ref: force_direct.cu:10-85): in the symmetric (action = -reaction) kernel every contribution to a body
- * goes to a slot of its own and the slots are added in a fixed order.  enable = 0 switches to fp64 atomics
- * instead (their order varies from launch to launch: fp32 results differ in the last bit now and then).
- * The slots cost 24 (N / (512 R) + splits) bytes per body of workspace (3.4 GB at N = 2^20) and 0.2 % of
- * time for equal masses, 1 % for general masses (measured at N = 2^20: 155.0 vs 154.6 ms and 171.9 vs
- * 170.3 ms per launch; the general-mass kernel then keeps 12 bodies per lane instead of 16); above 24 GiB
- * of slots (N > ~2.7 M) the atomic form is used regardless.  The one-sided kernel (N < 12,288, rectangular
- * sets) is reproducible anyway; the
- * two-set kernel of the sharded path keeps its atomics.  On by default. */
-NBODY_HIP_API int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int enable);
+/* Direct forces are bitwise reproducible, like the reference's one-thread-per-body loop
+ * (ref: force_direct.cu:10-85): in the symmetric (action = -reaction) kernels every contribution to a body
+ * goes to a slot of its own and the slots are added in a fixed order.
+ *   mode 1 (default)  slot planes when they fit the budget -- 24 GiB AND a quarter of the device memory that is
+ *                     free when the workspace has to grow -- otherwise fp64 atomics (their order varies from
+ *                     launch to launch: fp32 results differ in the last bit now and then); an allocation
+ *                     failure of the slot planes also falls back to the atomic form.  nbody_hip_direct_info
+ *                     tells which form a call at a given size takes, and which one the last call took;
+ *   mode 2            slot planes REQUIRED: a call that cannot have them fails with NBODY_HIP_ERR_RESOURCE
+ *                     instead of switching silently;
+ *   mode 0            fp64 atomics; the slot planes the context holds are given back at once.
+ * Slot planes: a reaction is one fp32 number per component (12 bytes per body and partner superblock), an
+ * I-side sum is fp64 (24 bytes per body and split): 12 D + 24 splits bytes per body with D = N / (512 R) --
+ * 1.9 GB at N = 2^20 (round 2: 3.4 GB), ~14 GB at N = 2^22; a workspace more than four times larger than the
+ * current call needs is released first.  Time against the atomic form at N = 2^20: see DESIGN.md section 4.1.
+ * The one-sided kernel (N < 12,288, rectangular sets) is reproducible anyway; the two-set kernel of the
+ * sharded path follows the same switch (splits I-side slots per body of the first set, N_first / (256 R)
+ * reaction slots per body of the second). */
+NBODY_HIP_API int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int mode);
+
+/* Most bytes of slot planes the deterministic form may take on this context (default and bytes = 0: 24 GiB;
+ * a quarter of the free device memory is the second limit whatever this says).  For shared GPUs. */
+NBODY_HIP_API int nbody_hip_direct_slot_budget(nbody_hip_ctx* ctx, unsigned long long bytes);
+
+/* What a Direct all-pairs call at `count` bodies runs with the context's current settings (plain host
+ * arithmetic + one hipMemGetInfo when the workspace would have to grow), and what the last call ran.
+ * ctx may be NULL: the answer for a context with default settings from the fixed budget alone (no device needed). */
+typedef struct nbody_hip_direct_info_t {
+  int deterministic_mode;     /* the context's setting: 0, 1 or 2 (see nbody_hip_direct_deterministic) */
+  int kernel;                 /* at `count` bodies: 0 one-sided, 1 symmetric + fp64 atomics, 2 symmetric + slot planes */
+  int bodies_per_lane_equal;  /* R of the equal-mass instantiation (symmetric kernels; else 0) */
+  int bodies_per_lane_general;/* R of the general-mass instantiation */
+  int reaction_slots;         /* D  (equal-mass shape) */
+  int iside_slots;            /* splits (equal-mass shape) */
+  int reserved0, reserved1;
+  unsigned long long workspace_bytes_needed;  /* accumulator workspace of such a call */
+  unsigned long long slot_bytes_wanted;       /* what the slot planes need (also when they were refused) */
+  unsigned long long workspace_bytes_held;    /* what the context holds right now */
+  int last_kernel;            /* what the last Direct call of this context ran (-1: none yet) */
+  int reserved2;
+} nbody_hip_direct_info_t;
+NBODY_HIP_API int nbody_hip_direct_info(nbody_hip_ctx* ctx, size_t count, float eps2, nbody_hip_direct_info_t* out);
 
 /* Tuning knobs for experiments.  variant: -1 automatic, 0 scalar body + LDS sources, 1 packed
  * (v_pk_*_f32) body + LDS sources, 2 scalar body + scalar-cache sources, 3 symmetric (action =

@@ -46,6 +46,15 @@ class ParticleDataStruct(C.Structure):
         "acc_old_x", "acc_old_y", "acc_old_z", "mass")] + [("count", C.c_size_t)]
 
 
+class DirectInfoStruct(C.Structure):
+    """nbody_hip_direct_info_t (include/nbody_hip.h)"""
+    _fields_ = [("deterministic_mode", C.c_int), ("kernel", C.c_int), ("bodies_per_lane_equal", C.c_int),
+                ("bodies_per_lane_general", C.c_int), ("reaction_slots", C.c_int), ("iside_slots", C.c_int),
+                ("reserved0", C.c_int), ("reserved1", C.c_int), ("workspace_bytes_needed", C.c_ulonglong),
+                ("slot_bytes_wanted", C.c_ulonglong), ("workspace_bytes_held", C.c_ulonglong),
+                ("last_kernel", C.c_int), ("reserved2", C.c_int)]
+
+
 FIELDS = tuple(n for n, _ in ParticleDataStruct._fields_[:13])
 
 # every symbol include/nbody_hip.h declares: name -> (restype, argtypes)
@@ -123,11 +132,13 @@ PROTOTYPES = {
     "nbody_hip_tree_build_packed": (C.c_int, [_P, _P, C.c_size_t]),
     "nbody_hip_tree_compute_forces_packed": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_float, _P]),
     "nbody_hip_tree_stats": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float),
-                                       C.POINTER(C.c_ulonglong), C.POINTER(C.c_int * 12)]),
+                                       C.POINTER(C.c_ulonglong), C.POINTER(C.c_int * 24)]),
     "nbody_hip_tree_copy_nodes": (C.c_int, [_P, _P, C.c_int, _P]),
     "nbody_hip_time_direct_packed": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_float,
                                                C.c_float, C.c_int, C.POINTER(C.c_float)]),
     "nbody_hip_direct_deterministic": (C.c_int, [_P, C.c_int]),
+    "nbody_hip_direct_slot_budget": (C.c_int, [_P, C.c_ulonglong]),
+    "nbody_hip_direct_info": (C.c_int, [_P, C.c_size_t, C.c_float, _P]),
     "nbody_hip_direct_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
 }
 

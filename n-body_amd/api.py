@@ -145,9 +145,23 @@ class Context:
     def tuning(self, variant=-1, targets_per_lane=0, source_splits=0):
         check(self._lib.nbody_hip_direct_tuning(self._h, variant, targets_per_lane, source_splits))
 
-    def deterministic(self, enable: bool = True):
-        """Direct forces bitwise reproducible at every size (nbody_hip_direct_deterministic)."""
-        check(self._lib.nbody_hip_direct_deterministic(self.handle, 1 if enable else 0))
+    def deterministic(self, mode=True):
+        """Direct forces bitwise reproducible (nbody_hip_direct_deterministic): 0 / False = fp64 atomics, 1 / True =
+        slot planes when they fit the budget (default), 2 = slot planes required (else ResourceException)."""
+        check(self._lib.nbody_hip_direct_deterministic(self.handle, int(mode)))
+
+    def slotBudget(self, nbytes: int = 0):
+        """most bytes of slot planes the deterministic Direct form may take (0 = default, 24 GiB)"""
+        check(self._lib.nbody_hip_direct_slot_budget(self.handle, nbytes))
+
+    def directInfo(self, count: int = 0, eps2: float = 1.0) -> dict:
+        """What a Direct all-pairs call at `count` bodies runs, and what the last call ran (nbody_hip_direct_info)."""
+        from ._lib import DirectInfoStruct
+        s = DirectInfoStruct()
+        check(self._lib.nbody_hip_direct_info(self.handle, count, eps2, C.byref(s)))
+        out = {k: getattr(s, k) for k, _ in DirectInfoStruct._fields_ if not k.startswith("reserved")}
+        out["kernel_name"] = ("one-sided", "symmetric+atomics", "symmetric+slots")[s.kernel]
+        return out
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -666,7 +680,7 @@ class BarnesHutTree:
 
     def stats(self):
         nc, rm, nv = C.c_int(), C.c_float(), C.c_ulonglong()
-        lb = (C.c_int * 12)()
+        lb = (C.c_int * 24)()  # NBODY_HIP_TREE_LEVELS
         check(self.ctx._lib.nbody_hip_tree_stats(self._h, C.byref(nc), C.byref(rm), C.byref(nv),
                                                  C.byref(lb)))
         return {"node_count": nc.value, "root_mass": rm.value, "nodes_visited": nv.value,

@@ -34,12 +34,27 @@ int Workspace::reserve(size_t want) {
   size_t cap = bytes + bytes / 2;
   if (cap < want) cap = want;
   cap = (cap + 255) & ~(size_t)255;
-  void* p = nullptr;
-  NBH_HIP(hipMalloc(&p, cap));
+  want = (want + 255) & ~(size_t)255;
   if (ptr) {
-    // queued work may still read the old buffer
+    // the old buffer goes first (its contents are never carried over), so that old + new are not held
+    // together at the peak; queued work may still read it
     NBH_HIP(hipDeviceSynchronize());
     NBH_HIP(hipFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+    generation++;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cap);
+  if (e != hipSuccess && cap > want) {  // the geometric head-room is a convenience, not a need
+    (void)hipGetLastError();
+    cap = want;
+    e = hipMalloc(&p, cap);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return ::nbh::fail(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE, __FILE__, __LINE__,
+                       "hipMalloc(%zu bytes of workspace): %s", cap, hipGetErrorString(e));
   }
   ptr = p;
   bytes = cap;
@@ -47,7 +62,7 @@ int Workspace::reserve(size_t want) {
   return NBODY_HIP_OK;
 }
 
-void Workspace::release() {
+void Workspace::release() {  // the caller has made sure nothing queued still uses the buffer
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr;
   bytes = 0;
@@ -379,9 +394,52 @@ extern "C" int nbody_hip_time_direct_packed(nbody_hip_ctx* ctx, const nbody_floa
   return NBODY_HIP_OK;
 }
 
-extern "C" int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int enable) {
+extern "C" int nbody_hip_direct_deterministic(nbody_hip_ctx* ctx, int mode) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
-  ctx->deterministic = enable != 0;
+  if (mode < 0 || mode > 2) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "mode must be 0 (atomics), 1 (slots when they fit) or 2 (slots required)");
+  ctx->deterministic = mode;
+  // the slot planes are the one big allocation of this library: give them back when they are switched off
+  if (mode == 0 && ctx->partial.bytes > ((size_t)64 << 20) && !ctx->capturing) {
+    NBH_HIP(hipSetDevice(ctx->device));
+    NBH_HIP(hipDeviceSynchronize());
+    ctx->partial.release();
+  }
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_direct_slot_budget(nbody_hip_ctx* ctx, unsigned long long bytes) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  ctx->det_budget = bytes ? (size_t)bytes : ((size_t)24 << 30);
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_direct_info(nbody_hip_ctx* ctx, size_t count, float eps2, nbody_hip_direct_info_t* out) {
+  if (!out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  // ctx == NULL: the plan of a context with default settings, from the fixed budget alone (no device needed:
+  // what the CPU-side tests of the shape / budget arithmetic call)
+  const nbody_hip_ctx defaults{};
+  const nbody_hip_ctx* c = ctx ? ctx : &defaults;
+  memset(out, 0, sizeof(*out));
+  out->deterministic_mode = c->deterministic;
+  out->last_kernel = c->last_direct_kernel;
+  out->workspace_bytes_held = c->partial.bytes;
+  if (count == 0) return NBODY_HIP_OK;
+  if (count > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count exceeds 2^30");
+  // the hipMemGetInfo of the budget test needs the context's device current
+  const bool dev = ctx && nbody_hip_device_count() > 0 && hipSetDevice(ctx->device) == hipSuccess;
+  DirectPlan p = direct_plan(c, count, dev);
+  if (!(eps2 >= 1e-12f)) p.symmetric = false;  // the guard variant of the one-sided kernel handles tiny softening
+  if (!p.symmetric) {
+    out->kernel = 0;
+    return NBODY_HIP_OK;
+  }
+  out->kernel = p.det ? 2 : 1;
+  out->bodies_per_lane_equal = p.eq.R;
+  out->bodies_per_lane_general = p.gen.R;
+  out->reaction_slots = p.det ? p.eq.D : 0;
+  out->iside_slots = p.det ? p.eq.splits : 1;
+  out->workspace_bytes_needed = p.bytes;
+  out->slot_bytes_wanted = p.det_bytes_wanted;
   return NBODY_HIP_OK;
 }
 

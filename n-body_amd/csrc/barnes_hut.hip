@@ -1519,7 +1519,7 @@ extern "C" int nbody_hip_tree_walk_form(nbody_hip_tree* g, int form) {
 
 extern "C" int nbody_hip_tree_stats(nbody_hip_tree* g, int* node_count, float* root_mass,
                                     unsigned long long* nodes_visited_per_wave_total,
-                                    int level_base_out[12]) {
+                                    int level_base_out[NBODY_HIP_TREE_LEVELS]) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
   if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "tree has not been built");
   nbody_hip_ctx* ctx = g->ctx;
@@ -1530,7 +1530,7 @@ extern "C" int nbody_hip_tree_stats(nbody_hip_tree* g, int* node_count, float* r
   NBH_HIP(hipMemcpy(lb, g->d_level_base, sizeof(lb), hipMemcpyDeviceToHost));
   if (node_count) *node_count = lb[g->max_depth + 1];
   if (level_base_out)
-    for (int k = 0; k < 12; k++) level_base_out[k] = k <= g->max_depth + 1 ? lb[k] : lb[g->max_depth + 1];
+    for (int k = 0; k < NBODY_HIP_TREE_LEVELS; k++) level_base_out[k] = k <= g->max_depth + 1 ? lb[k] : lb[g->max_depth + 1];
   if (root_mass) {
     NodeRec r;
     NBH_HIP(hipMemcpy(&r, g->t.rec, sizeof(r), hipMemcpyDeviceToHost));

@@ -87,7 +87,11 @@ struct nbody_hip_ctx {
   mutable bool capture_failed = false;           // a non-capturable call was made while recording
   // tuning overrides (variant -1 / others 0 = automatic)
   int tune_variant = -1, tune_tpl = 0, tune_splits = 0;
-  bool deterministic = true;   // symmetric all-pairs kernel: slot planes + fixed-order sum instead of fp64 atomics
+  // symmetric kernels: 0 = fp64 atomics; 1 = slot planes + fixed-order sum (bitwise reproducible) when they fit the
+  // budget, else atomics; 2 = slot planes REQUIRED (a call that cannot have them fails with NBODY_HIP_ERR_RESOURCE)
+  int deterministic = 1;
+  size_t det_budget = (size_t)24 << 30;  // most slot-plane bytes the deterministic form may take (nbody_hip_direct_slot_budget)
+  int last_direct_kernel = -1;  // what the last Direct launch ran: 0 one-sided, 1 symmetric + atomics, 2 symmetric + slots
   // bumped when a tree / grid of this context re-sizes or frees device arrays a recorded step graph
   // may point into; together with the workspaces' generations it dates a recording
   unsigned long long alloc_generation = 0;
@@ -106,6 +110,27 @@ namespace nbh {
 __device__ __forceinline__ float kick1(float v, float a_old, float a_new, float dt_half) {
   return __builtin_fmaf(a_old + a_new, dt_half, v);
 }
+
+// direct_sym.hip: launch shape of the symmetric all-pairs kernel for a given number of bodies per lane, and what
+// a Direct call at n bodies will run (plain host arithmetic; nbody_hip_direct_info exports it)
+struct SymShape {
+  int R, NB, D, per, splits;
+  size_t plane;
+  size_t reaction_bytes() const;  // D x 3 float planes, 256-byte aligned
+  size_t det_bytes() const;       // + splits x 3 double planes
+  size_t atomic_bytes() const;    // 3 double planes
+};
+struct DirectPlan {
+  bool symmetric = false;         // false: one-sided kernel (direct.hip)
+  bool det = false;               // slot planes
+  SymShape eq{}, gen{};           // equal-mass / general-mass instantiation
+  size_t bytes = 0;               // workspace the call needs
+  size_t det_bytes_wanted = 0;    // what the slot planes would need (also when they were refused)
+};
+constexpr int kDetGenR = 12;      // bodies per lane of the general-mass instantiation in deterministic mode at sizes
+                                  // where the equal-mass one takes 16
+SymShape sym_shape(const nbody_hip_ctx* ctx, size_t n, int R);
+DirectPlan direct_plan(const nbody_hip_ctx* ctx, size_t n, bool query_device);
 
 // direct.hip
 int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,

@@ -318,6 +318,7 @@ int direct_packed(nbody_hip_ctx* ctx, const float4* targets, size_t n_targets,
     return direct_symmetric(ctx, targets, n_targets, G, eps2, acc4, accumulate, ax, ay, az, vx, vy,
                             vz, aox, aoy, aoz, half_dt);
 
+  ctx->last_direct_kernel = 0;
   const Shape s = choose_shape(ctx, n_targets, n_sources);
   int rc = ctx->partial.reserve((size_t)s.splits * s.n_tgt_pad * sizeof(float4));
   if (rc) return rc;

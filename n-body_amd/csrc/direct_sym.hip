@@ -56,21 +56,28 @@ __device__ __forceinline__ float wave_rot1(float v) {
 #endif
 constexpr int kSymBlocksPerCU = 16;  // workgroups aimed at per CU (tools/sweep_mid.py)
 constexpr int kSymMinChunks = 4;     // at least 4 chunks (256 J bodies) per workgroup
-constexpr size_t kDetBudgetBytes = (size_t)24 << 30;  // slot planes of the deterministic mode: at most 24 GiB
-                                                      // (= 3.2e9 doubles: element offsets fit 32 bits)
 constexpr float kFar = 1.0e18f;  // padding bodies sit here: (3e36)^-3/2 underflows to 0, no mass test needed
 
-// DET (all-pairs form only): deterministic sums.  Instead of fp64 atomics every contribution gets a slot
-// of its own -- the reaction of the partner at ring offset d goes to slot d - 1 of the receiving body,
-// the I-side sum of split s to slot D + s -- written once with plain (coalesced) stores; the finalize
-// kernel adds a body's slots in a fixed order.  Bitwise reproducible like the reference's one-thread-
-// per-body loop (force_direct.cu:10-85) at the price of 12 N^2 / S bytes of slot planes.
+// DET: deterministic sums.  Instead of fp64 atomics every contribution gets a slot of its own, written once
+// with plain (coalesced) stores; the finalize kernel adds a body's slots in a fixed order.  Bitwise
+// reproducible like the reference's one-thread-per-body loop (force_direct.cu:10-85).
+//   all pairs : the reaction of the partner at ring offset d -> REACTION slot d - 1 of the receiving body,
+//               the I-side sum of split s -> I-SIDE slot s of the body's own superblock;
+//   two sets  : the reaction of I superblock A on a J body -> reaction slot A of the J set, the I-side sum
+//               of split s -> I-side slot s of the I set.
+// A reaction is ONE fp32 number (the sum of the four waves' fp32 sums of a 64-step rotation), so its slot is
+// a float: 12 bytes per (body, partner) instead of the 24 of round 2; the I-side sums are fp64.  The equal-
+// mass factor m0 is applied by the finalize kernel.  Slot planes: 12 D + 24 splits bytes per body
+// (1.9 GB at N = 2^20, 16 bodies per lane: D = 128, 16 splits).
+//   acc64  : I-side accumulator -- atomics: [3][plane_i] doubles; DET: [splits][3][plane_i] doubles
+//   accj   : reaction accumulator -- atomics: [3][plane] doubles (all pairs: the same array as acc64; two sets:
+//            the J set's); DET: [D or NBI][3][plane] FLOATS
 template <int R, bool RECT, bool EQM, bool DET = false>
 __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const float4* __restrict__ posm, int n,
                                                             const float4* __restrict__ posj, int nj,
                                                             int NB, int NBJ, int chunks_per_split,
                                                             double* __restrict__ acc64,
-                                                            double* __restrict__ accj64,
+                                                            void* __restrict__ accj,
                                                             size_t plane_i, size_t plane_j,
                                                             const unsigned int* __restrict__ mass_range,
                                                             float eps2) {
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
       for (int r = 0; r < R; r++)
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          acc64[((size_t)(D + blockIdx.y) * 3 + c) * plane_i + (size_t)(A * S + r * kBlock + tid)] = 0.0;
+          acc64[((size_t)blockIdx.y * 3 + c) * plane_i + (size_t)(A * S + r * kBlock + tid)] = 0.0;
     }
     return;
   }
@@ -148,22 +155,24 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
   auto flush_chunk = [&](int q) {  // one wave: combine the four waves' sums of chunk q, add to global
     const int pd = (q0 + q) / CPB, pc = (q0 + q) % CPB;
     if constexpr (DET) {
-      if (pd > 0) {  // slot pd - 1 of the partner's bodies; a partner the half ring skips contributes zero
-        // (wave-uniform slot base; 32-bit element offsets: the slot planes stay below 2^32 doubles)
-        double* slot = acc64 + (size_t)(pd - 1) * 3 * plane_i;
-        const unsigned int j = (unsigned int)(((A + pd) % NB) * S + pc * 64 + lane), pl = (unsigned int)plane_i;
+      if (RECT || pd > 0) {  // all pairs: slot pd - 1 of the partner's bodies (a partner the half ring skips
+        // contributes zero); two sets: slot A of the J bodies.  Wave-uniform slot base, 32-bit element offsets
+        // (a slot's three planes stay far below 2^32 floats)
+        const size_t plane = RECT ? plane_j : plane_i;
+        float* slot = static_cast<float*>(accj) + (size_t)(RECT ? A : pd - 1) * 3 * plane;
+        const unsigned int j = (unsigned int)((RECT ? pd : (A + pd) % NB) * S + pc * 64 + lane), pl = (unsigned int)plane;
         const int sb = q & 1;
-        const float keep = partner_valid(pd) ? m0 : 0.f;
+        const bool keep = partner_valid(pd);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const float v = (slab[sb][0][c][lane] + slab[sb][1][c][lane]) + (slab[sb][2][c][lane] + slab[sb][3][c][lane]);
-          slot[c * pl + j] = (double)v * (double)keep;
+          slot[c * pl + j] = keep ? v : 0.f;
         }
       }
     } else if ((RECT || pd > 0) && partner_valid(pd)) {
       const int j = (RECT ? pd : (A + pd) % NB) * S + pc * 64 + lane;
       const int sb = q & 1;
-      double* dst = RECT ? accj64 : acc64;
+      double* dst = RECT ? static_cast<double*>(accj) : acc64;
       const size_t plane = RECT ? plane_j : plane_i;
 #pragma unroll
       for (int c = 0; c < 3; c++) {  // component planes: 64 lanes x 8 B contiguous per atomic instruction
@@ -255,12 +264,12 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
     const double fx = LACC ? lacc[(0 * R + r) * kBlock + tid] : sx[LACC ? 0 : r];
     const double fy = LACC ? lacc[(1 * R + r) * kBlock + tid] : sy[LACC ? 0 : r];
     const double fz = LACC ? lacc[(2 * R + r) * kBlock + tid] : sz[LACC ? 0 : r];
-    if constexpr (DET) {
-      double* slot = acc64 + (size_t)(D + blockIdx.y) * 3 * plane_i;
+    if constexpr (DET) {  // (m0 is applied by the finalize kernel)
+      double* slot = acc64 + (size_t)blockIdx.y * 3 * plane_i;
       const unsigned int iu = (unsigned int)i, pl = (unsigned int)plane_i;
-      slot[iu] = fx * (double)m0;
-      slot[pl + iu] = fy * (double)m0;
-      slot[2u * pl + iu] = fz * (double)m0;
+      slot[iu] = fx;
+      slot[pl + iu] = fy;
+      slot[2u * pl + iu] = fz;
     } else {
       unsafeAtomicAdd(&acc64[(size_t)i], fx * (double)m0);
       unsafeAtomicAdd(&acc64[plane_i + (size_t)i], fy * (double)m0);
@@ -297,26 +306,43 @@ __global__ __launch_bounds__(kBlock) void mass_range_kernel(const float4* __rest
   }
 }
 
-// acc = G * acc64 ; SoA or float4 output ; optional fused Velocity-Verlet kick
+// Where a body's contributions lie: n_i I-side slots (fp64, [slot][3][plane]) and n_r reaction slots (fp32, same
+// shape).  Atomic mode: one fp64 slot that already holds everything (n_i = 1, n_r = 0).
+struct SlotLayout {
+  const double* isl;
+  const float* rsl;
+  size_t plane;
+  int n_i, n_r;
+};
+
+// acc = G * (sum of the body's slots, in a fixed order) ; SoA or float4 output ; optional fused Velocity-Verlet kick
+// apply_m0: deterministic mode -- the equal-mass kernel stores its sums without the common mass factor
 __global__ __launch_bounds__(kBlock) void direct_sym_finalize_kernel(
-    const double* __restrict__ acc64, size_t plane, int nslots, size_t plane_gen, int nslots_gen,
-    const unsigned int* __restrict__ mass_range, int n, float G, float4* __restrict__ acc4, int accumulate,
-    float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, float* __restrict__ vx,
-    float* __restrict__ vy, float* __restrict__ vz, const float* __restrict__ aox,
+    SlotLayout eq, SlotLayout gen, int apply_m0, const unsigned int* __restrict__ mass_range, int n, float G,
+    float4* __restrict__ acc4, int accumulate, float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az,
+    float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz, const float* __restrict__ aox,
     const float* __restrict__ aoy, const float* __restrict__ aoz, float half_dt) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  SlotLayout L = eq;
+  double m0 = 1.0;
   if (mass_range) {  // the general-mass instantiation ran with a layout of its own (other bodies per lane)
     const bool uniform = mass_range[0] == mass_range[1] && mass_range[2] == mass_range[3] &&
                          mass_range[0] == mass_range[2] && ordered_to_float(mass_range[0]) > 0.f;
-    if (!uniform) { plane = plane_gen; nslots = nslots_gen; }
+    if (!uniform) L = gen;
+    else if (apply_m0) m0 = (double)ordered_to_float(mass_range[0]);
   }
   double sx = 0.0, sy = 0.0, sz = 0.0;
-  for (int k = 0; k < nslots; k++) {  // one slot with atomics; the deterministic mode's slots in a fixed order
-    const double* p = acc64 + (size_t)k * 3 * plane;
-    sx += p[i]; sy += p[plane + i]; sz += p[2 * plane + i];
+  for (int k = 0; k < L.n_r; k++) {
+    const float* p = L.rsl + (size_t)k * 3 * L.plane;
+    sx += (double)p[i]; sy += (double)p[L.plane + i]; sz += (double)p[2 * L.plane + i];
   }
-  const float fx = (float)((double)G * sx), fy = (float)((double)G * sy), fz = (float)((double)G * sz);
+  for (int k = 0; k < L.n_i; k++) {
+    const double* p = L.isl + (size_t)k * 3 * L.plane;
+    sx += p[i]; sy += p[L.plane + i]; sz += p[2 * L.plane + i];
+  }
+  const double gm = (double)G * m0;
+  const float fx = (float)(gm * sx), fy = (float)(gm * sy), fz = (float)(gm * sz);
   if (acc4) {
     float4 o = make_float4(fx, fy, fz, 0.f);
     if (accumulate) { const float4 c = acc4[i]; o.x += c.x; o.y += c.y; o.z += c.z; }
@@ -339,15 +365,15 @@ static void launch_mass_range(nbody_hip_ctx* ctx, const float4* pi, int ni, cons
   hipLaunchKernelGGL(mass_range_kernel, dim3(bj < 256 ? bj : 256), dim3(kBlock), 0, ctx->stream, pj, nj, enc + 2);
 }
 
-template <int R, bool RECT>
+template <int R, bool RECT, bool DET>
 static void launch_sym(nbody_hip_ctx* ctx, dim3 grid, const float4* pi, int ni, const float4* pj, int nj,
-                       int NB, int NBJ, int per, double* acci, double* accj, const unsigned int* enc,
+                       int NB, int NBJ, int per, double* acci, void* accj, const unsigned int* enc,
                        float eps2) {
   const size_t S = (size_t)kBlock * R;
   // both instantiations are queued; the one whose mass assumption does not hold exits at once
-  hipLaunchKernelGGL((direct_sym_kernel<R, RECT, true>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
+  hipLaunchKernelGGL((direct_sym_kernel<R, RECT, true, DET>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
                      NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
-  hipLaunchKernelGGL((direct_sym_kernel<R, RECT, false>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
+  hipLaunchKernelGGL((direct_sym_kernel<R, RECT, false, DET>), grid, dim3(kBlock), 0, ctx->stream, pi, ni, pj, nj,
                      NB, NBJ, per, acci, accj, (size_t)NB * S, (size_t)NBJ * S, enc, eps2);
 }
 
@@ -370,11 +396,10 @@ static int sym_R(const nbody_hip_ctx* ctx, size_t n, bool two_sets) {
   return n >= 200000 ? 16 : (n >= 100000 ? 12 : (n >= 28000 ? 8 : 6));  // (6: tools/sweep_mid.py, 12,288 bodies 0.064 vs 0.076 ms at 4)
 }
 
-namespace {
-struct SymShape {  // launch shape of the all-pairs kernel for a given number of bodies per lane
-  int R, NB, D, per, splits;
-  size_t plane;
-};
+// ---- launch shapes and the slot-plane budget: plain host arithmetic, also exported through
+// ---- nbody_hip_direct_info so that callers (and the CPU tests) can see what a call will do
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 SymShape sym_shape(const nbody_hip_ctx* ctx, size_t n, int R) {
   SymShape c;
   c.R = R;
@@ -393,22 +418,76 @@ SymShape sym_shape(const nbody_hip_ctx* ctx, size_t n, int R) {
   c.plane = (size_t)c.NB * S;
   return c;
 }
+// slot planes of the deterministic all-pairs form: D reaction slots (3 float planes) then `splits` I-side slots
+// (3 double planes), the second block 256-byte aligned
+size_t SymShape::reaction_bytes() const { return align256((size_t)D * 3 * plane * sizeof(float)); }
+size_t SymShape::det_bytes() const { return reaction_bytes() + (size_t)splits * 3 * plane * sizeof(double); }
+size_t SymShape::atomic_bytes() const { return 3 * plane * sizeof(double); }
+
+// May the deterministic form take `bytes` of slot planes?  They must fit the context's budget and, unless the
+// context already holds them, a quarter of the memory that is free on the device right now (plus what the
+// workspace would give back) -- on a shared or smaller GPU the atomic form is the better citizen.
+static bool det_budget_allows(const nbody_hip_ctx* ctx, size_t bytes, size_t* free_now) {
+  if (free_now) *free_now = 0;
+  if (bytes > ctx->det_budget) return false;
+  if (bytes <= ctx->partial.bytes) return true;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;  // cannot tell: try, the allocation failure path falls back
+  }
+  if (free_now) *free_now = free_b;
+  return bytes <= (free_b + ctx->partial.bytes) / 4;
+}
+
+DirectPlan direct_plan(const nbody_hip_ctx* ctx, size_t n, bool query_device) {
+  DirectPlan p;
+  p.symmetric = symmetric_pays(ctx, n);
+  p.eq = sym_shape(ctx, n, sym_R(ctx, n, false));
+  p.gen = p.eq;
+  p.det = false;
+  p.bytes = 0;
+  if (!p.symmetric) return p;
+  if (ctx->deterministic) {
+    // general masses at 16 bodies per lane: the slot stores push the kernel past the 256 architectural registers
+    // (191 ms against 170 ms with atomics at N = 2^20); 12 bodies per lane (78 KiB of LDS = two workgroups per CU)
+    // run it in 172 ms where 8 take 177 (tools/direct_det_probe.py, same box)
+    SymShape gen = (p.eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, kDetGenR) : p.eq;
+    size_t need = p.eq.det_bytes() > gen.det_bytes() ? p.eq.det_bytes() : gen.det_bytes();
+    bool ok = query_device ? det_budget_allows(ctx, need, nullptr) : need <= ctx->det_budget;
+    if (!ok && gen.R != p.eq.R) {  // the general-mass shape has more slots: try with the common shape
+      gen = p.eq;
+      need = p.eq.det_bytes();
+      ok = query_device ? det_budget_allows(ctx, need, nullptr) : need <= ctx->det_budget;
+    }
+    if (ok) {
+      p.det = true;
+      p.gen = gen;
+      p.bytes = need;
+    }
+    p.det_bytes_wanted = need;
+  }
+  if (!p.det) p.bytes = p.eq.atomic_bytes();
+  return p;
+}
+
+namespace {
 template <int R, bool EQM, bool DET>
-void launch_all_pairs(nbody_hip_ctx* ctx, const SymShape& c, const float4* posm, int n, double* acc64,
+void launch_all_pairs(nbody_hip_ctx* ctx, const SymShape& c, const float4* posm, int n, double* acci, void* accj,
                       const unsigned int* enc, float eps2) {
   hipLaunchKernelGGL((direct_sym_kernel<R, false, EQM, DET>), dim3(c.NB, c.splits), dim3(kBlock), 0, ctx->stream, posm, n,
-                     posm, n, c.NB, c.NB, c.per, acc64, acc64, c.plane, c.plane, enc, eps2);
+                     posm, n, c.NB, c.NB, c.per, acci, accj, c.plane, c.plane, enc, eps2);
 }
 template <bool EQM, bool DET>
-void launch_all_pairs_R(nbody_hip_ctx* ctx, const SymShape& c, const float4* posm, int n, double* acc64,
+void launch_all_pairs_R(nbody_hip_ctx* ctx, const SymShape& c, const float4* posm, int n, double* acci, void* accj,
                         const unsigned int* enc, float eps2) {
   switch (c.R) {
-    case 2: launch_all_pairs<2, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
-    case 6: launch_all_pairs<6, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
-    case 8: launch_all_pairs<8, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
-    case 12: launch_all_pairs<12, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
-    case 16: launch_all_pairs<16, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
-    default: launch_all_pairs<4, EQM, DET>(ctx, c, posm, n, acc64, enc, eps2); break;
+    case 2: launch_all_pairs<2, EQM, DET>(ctx, c, posm, n, acci, accj, enc, eps2); break;
+    case 6: launch_all_pairs<6, EQM, DET>(ctx, c, posm, n, acci, accj, enc, eps2); break;
+    case 8: launch_all_pairs<8, EQM, DET>(ctx, c, posm, n, acci, accj, enc, eps2); break;
+    case 12: launch_all_pairs<12, EQM, DET>(ctx, c, posm, n, acci, accj, enc, eps2); break;
+    case 16: launch_all_pairs<16, EQM, DET>(ctx, c, posm, n, acci, accj, enc, eps2); break;
+    default: launch_all_pairs<4, EQM, DET>(ctx, c, posm, n, acci, accj, enc, eps2); break;
   }
 }
 }  // namespace
@@ -418,46 +497,66 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
                      float* vy, float* vz, const float* aox, const float* aoy, const float* aoz,
                      float half_dt) {
   // Both instantiations (equal masses / general masses) are queued; the one whose assumption about the
-  // masses fails exits at once (decided on the device).  Each has a launch shape of its own:
-  const SymShape eq = sym_shape(ctx, n, sym_R(ctx, n, false));
-  // deterministic mode: one slot per contribution (D reaction slots + one I-side slot per split); every
-  // slot is written exactly once by the kernel, so nothing has to be cleared.  It needs 24 (D + splits)
-  // bytes per body: taken when asked for (nbody_hip_direct_deterministic) and it fits the budget
-  const bool det = ctx->deterministic &&
-                   (size_t)(eq.D + eq.splits) * eq.plane * 3 * sizeof(double) <= kDetBudgetBytes;
-  // general masses at 16 bodies per lane: the slot stores push the kernel from 277 to 285 registers (191 ms
-  // against 170 ms with atomics at N = 2^20); 12 bodies per lane (248 registers, 78 KiB of LDS = two workgroups
-  // per CU) run it in 178 ms where 8 take 184 (tools/direct_det_probe.py, same box)
-  SymShape gen = (det && eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, 12) : eq;
-  if ((size_t)(gen.D + gen.splits) * gen.plane * 3 * sizeof(double) > kDetBudgetBytes) gen = eq;  // more slots: keep the budget
-  const int nslots_eq = det ? eq.D + eq.splits : 1, nslots_gen = det ? gen.D + gen.splits : 1;
-  const size_t bytes_eq = (size_t)nslots_eq * eq.plane * 3 * sizeof(double);
-  const size_t bytes_gen = (size_t)nslots_gen * gen.plane * 3 * sizeof(double);
-  const size_t acc_bytes = bytes_eq > bytes_gen ? bytes_eq : bytes_gen;  // three component planes per slot
-  if (int rc = ctx->partial.reserve(acc_bytes)) return rc;
-  double* acc64 = static_cast<double*>(ctx->partial.ptr);
-  if (!det) NBH_HIP(hipMemsetAsync(acc64, 0, acc_bytes, ctx->stream));
-  if (int rc = ctx->reduce.reserve(64)) return rc;
+  // masses fails exits at once (decided on the device).  Each has a launch shape of its own.
+  // Deterministic mode: one slot per contribution; every slot is written exactly once by the kernel, so
+  // nothing has to be cleared.  Taken when asked for (nbody_hip_direct_deterministic) and the slot planes fit
+  // the budget (det_budget_allows); "required" (mode 2) turns a miss into an error instead of the atomic form.
+  DirectPlan plan = direct_plan(ctx, n, true);
+  if (ctx->deterministic == 2 && !plan.det)
+    return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "deterministic Direct sums were required but their slot planes (%zu bytes "
+                    "for %zu bodies) exceed the budget (%zu bytes and a quarter of the free device memory)",
+                    plan.det_bytes_wanted, n, ctx->det_budget);
+  // a workspace left over from a much larger problem is given back first (the slot planes are the one big
+  // allocation of this library)
+  if (ctx->partial.bytes > ((size_t)64 << 20) && ctx->partial.bytes / 4 > plan.bytes && !ctx->capturing) {
+    NBH_HIP(hipDeviceSynchronize());
+    ctx->partial.release();
+  }
+  int rc = ctx->partial.reserve(plan.bytes);
+  if (rc != NBODY_HIP_OK && plan.det && ctx->deterministic != 2) {
+    // the slot planes could not be had after all: the atomic form needs 24 bytes per body
+    (void)hipGetLastError();
+    plan.det = false;
+    plan.gen = plan.eq;
+    plan.bytes = plan.eq.atomic_bytes();
+    rc = ctx->partial.reserve(plan.bytes);
+  }
+  if (rc != NBODY_HIP_OK) return rc;
+  const SymShape &eq = plan.eq, &gen = plan.gen;
+  const bool det = plan.det;
+  char* base = static_cast<char*>(ctx->partial.ptr);
+  if (!det) NBH_HIP(hipMemsetAsync(base, 0, plan.bytes, ctx->stream));
+  if (int rc2 = ctx->reduce.reserve(64)) return rc2;
   unsigned int* enc = static_cast<unsigned int*>(ctx->reduce.ptr);
   const int ni = (int)n;
   launch_mass_range(ctx, posm, ni, posm, ni, enc);
+  SlotLayout Leq, Lgen;
   if (det) {
-    launch_all_pairs_R<true, true>(ctx, eq, posm, ni, acc64, enc, eps2);
-    launch_all_pairs_R<false, true>(ctx, gen, posm, ni, acc64, enc, eps2);
+    // [reaction slots: D x 3 float planes][I-side slots: splits x 3 double planes], one layout per instantiation
+    // (only one of the two runs; they share the workspace)
+    Leq = SlotLayout{reinterpret_cast<const double*>(base + eq.reaction_bytes()), reinterpret_cast<const float*>(base),
+                     eq.plane, eq.splits, eq.D};
+    Lgen = SlotLayout{reinterpret_cast<const double*>(base + gen.reaction_bytes()), reinterpret_cast<const float*>(base),
+                      gen.plane, gen.splits, gen.D};
+    launch_all_pairs_R<true, true>(ctx, eq, posm, ni, const_cast<double*>(Leq.isl), base, enc, eps2);
+    launch_all_pairs_R<false, true>(ctx, gen, posm, ni, const_cast<double*>(Lgen.isl), base, enc, eps2);
   } else {
-    launch_all_pairs_R<true, false>(ctx, eq, posm, ni, acc64, enc, eps2);
-    launch_all_pairs_R<false, false>(ctx, gen, posm, ni, acc64, enc, eps2);
+    Leq = Lgen = SlotLayout{reinterpret_cast<const double*>(base), nullptr, eq.plane, 1, 0};
+    launch_all_pairs_R<true, false>(ctx, eq, posm, ni, reinterpret_cast<double*>(base), base, enc, eps2);
+    launch_all_pairs_R<false, false>(ctx, gen, posm, ni, reinterpret_cast<double*>(base), base, enc, eps2);
   }
   NBH_LAUNCH_CHECK();
+  ctx->last_direct_kernel = det ? 2 : 1;
   const int fblocks = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, acc64, eq.plane,
-                     nslots_eq, gen.plane, nslots_gen, enc, ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy,
-                     aoz, half_dt);
+  hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3(fblocks), dim3(kBlock), 0, ctx->stream, Leq, Lgen, det ? 1 : 0, enc,
+                     ni, G, acc4, accumulate, ax, ay, az, vx, vy, vz, aox, aoy, aoz, half_dt);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
 
 // Two disjoint sets: acc_i (+)= forces on I from J ; acc_j = forces on J from I (the reactions).
+// Deterministic form (same switch as the all-pairs kernel): `splits` fp64 I-side slots per I body, NBI fp32
+// reaction slots per J body -- a sharded run is then reproducible launch after launch too.
 int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const float4* pj, size_t nj,
                           float G, float eps2, float4* acc_i, int accumulate_i, float4* acc_j,
                           int accumulate_j) {
@@ -472,29 +571,56 @@ int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const
   if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);
   splits = (total + per - 1) / per;
   const size_t plane_i = (size_t)NBI * S, plane_j = (size_t)NBJ * S;
-  const size_t bi = plane_i * 3 * sizeof(double), bj = plane_j * 3 * sizeof(double);
-  if (int rc = ctx->partial.reserve(bi + bj)) return rc;
-  double* acci = static_cast<double*>(ctx->partial.ptr);
-  double* accj = acci + plane_i * 3;
-  NBH_HIP(hipMemsetAsync(acci, 0, bi + bj, ctx->stream));
-  if (int rc = ctx->reduce.reserve(64)) return rc;
+  const size_t det_i = align256((size_t)splits * 3 * plane_i * sizeof(double));
+  const size_t det_j = (size_t)NBI * 3 * plane_j * sizeof(float);
+  bool det = ctx->deterministic != 0 && det_budget_allows(ctx, det_i + det_j, nullptr);
+  if (ctx->deterministic == 2 && !det)
+    return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "deterministic Direct sums were required but their slot planes (%zu bytes) "
+                    "exceed the budget", det_i + det_j);
+  const size_t bi = align256(plane_i * 3 * sizeof(double)), bj = plane_j * 3 * sizeof(double);
+  int rc = ctx->partial.reserve(det ? det_i + det_j : bi + bj);
+  if (rc != NBODY_HIP_OK && det && ctx->deterministic != 2) {
+    (void)hipGetLastError();
+    det = false;
+    rc = ctx->partial.reserve(bi + bj);
+  }
+  if (rc != NBODY_HIP_OK) return rc;
+  char* base = static_cast<char*>(ctx->partial.ptr);
+  double* acci = reinterpret_cast<double*>(base);
+  void* accj = base + (det ? det_i : bi);
+  if (!det) NBH_HIP(hipMemsetAsync(base, 0, bi + bj, ctx->stream));
+  if (int rc2 = ctx->reduce.reserve(64)) return rc2;
   unsigned int* enc = static_cast<unsigned int*>(ctx->reduce.ptr);
   launch_mass_range(ctx, pi, (int)ni, pj, (int)nj, enc);
   const dim3 grid(NBI, splits);
+#define NBH_PAIR_LAUNCH(RR)                                                                                          \
+  if (det) launch_sym<RR, true, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2);    \
+  else launch_sym<RR, true, false>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2)
   switch (R) {
-    case 2: launch_sym<2, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
-    case 6: launch_sym<6, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
-    case 8: launch_sym<8, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
-    case 16: launch_sym<16, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
-    default: launch_sym<4, true>(ctx, grid, pi, (int)ni, pj, (int)nj, NBI, NBJ, per, acci, accj, enc, eps2); break;
+    case 2: NBH_PAIR_LAUNCH(2); break;
+    case 6: NBH_PAIR_LAUNCH(6); break;
+    case 8: NBH_PAIR_LAUNCH(8); break;
+    case 16: NBH_PAIR_LAUNCH(16); break;
+    default: NBH_PAIR_LAUNCH(4); break;
   }
+#undef NBH_PAIR_LAUNCH
   NBH_LAUNCH_CHECK();
+  ctx->last_direct_kernel = det ? 2 : 1;
+  SlotLayout Li, Lj;
+  if (det) {
+    Li = SlotLayout{acci, nullptr, plane_i, splits, 0};
+    Lj = SlotLayout{nullptr, static_cast<const float*>(accj), plane_j, 0, NBI};
+  } else {
+    Li = SlotLayout{acci, nullptr, plane_i, 1, 0};
+    Lj = SlotLayout{static_cast<const double*>(accj), nullptr, plane_j, 1, 0};
+  }
+  // (mass_range is read for the equal-mass factor only in the deterministic form; the atomic form applied it)
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((ni + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, acci, plane_i, 1, plane_i, 1, nullptr, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+                     ctx->stream, Li, Li, det ? 1 : 0, det ? enc : nullptr, (int)ni, G, acc_i, accumulate_i, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   hipLaunchKernelGGL(direct_sym_finalize_kernel, dim3((unsigned)((nj + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     ctx->stream, accj, plane_j, 1, plane_j, 1, nullptr, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+                     ctx->stream, Lj, Lj, det ? 1 : 0, det ? enc : nullptr, (int)nj, G, acc_j, accumulate_j, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }

@@ -175,19 +175,19 @@ BarnesHutTree::BarnesHutTree(size_t max_particles) : max_particles_(max_particle
 BarnesHutTree::~BarnesHutTree() { nbody_hip_tree_destroy(handle()); }
 void BarnesHutTree::driftBuild(ParticleData* d, float dt) {
   NBODY_CHECK(nbody_hip_tree_drift_build(handle(), raw(d), dt));
-  int level_base[12];
+  int level_base[NBODY_HIP_TREE_LEVELS];
   NBODY_CHECK(nbody_hip_tree_stats(handle(), &node_count_, nullptr, nullptr, level_base));
   max_nodes_ = static_cast<size_t>(node_count_);
-  max_depth_ = 0;
-  for (int l = 1; l < 12; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
+  max_depth_ = 0;  // the deepest level that holds nodes (the reference reports the depth its insertion reached)
+  for (int l = 1; l < NBODY_HIP_TREE_LEVELS; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
 }
 void BarnesHutTree::build(const ParticleData* d) {
   NBODY_CHECK(nbody_hip_tree_build(handle(), raw(d)));
-  int level_base[12];
+  int level_base[NBODY_HIP_TREE_LEVELS];
   NBODY_CHECK(nbody_hip_tree_stats(handle(), &node_count_, nullptr, nullptr, level_base));
   max_nodes_ = static_cast<size_t>(node_count_);
-  max_depth_ = 0;
-  for (int l = 1; l < 12; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
+  max_depth_ = 0;  // the deepest level that holds nodes (the reference reports the depth its insertion reached)
+  for (int l = 1; l < NBODY_HIP_TREE_LEVELS; l++) if (level_base[l] > level_base[l - 1]) max_depth_ = l - 1;
 }
 void BarnesHutTree::computeForces(ParticleData* d, float theta, float G, float eps) {
   NBODY_CHECK(nbody_hip_tree_compute_forces(handle(), raw(d), theta, G, eps));

@@ -378,10 +378,14 @@ static inline float hash_dist2(float dx, float dy, float dz) { return fmaf(dz, d
 
 /* Forces on an EXPLICIT grid (origin bmin, dims): the sharded path bins every rank's bodies on
  * the global grid.  n_t <= n: only the first n_t bodies are targets (own bodies first, then halo). */
-ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float* x, const float* y,
-                                               const float* z, const float* m, float* ax, float* ay,
-                                               float* az, float G, float eps2, float cell_size,
-                                               float cutoff, const float bmin[3], const int dims[3]) {
+/* gold / abs_sum (optional, n_t x 3 doubles / n_t doubles): the same pair set (decided by the fp32 cutoff test)
+ * summed in fp64 arithmetic, and sum_j |t_ij| of the fp32 term vectors -- kappa_i = abs_sum_i / |a_i| is the
+ * condition number of body i's sum: every fp32 evaluation of the terms (this one, the reference's kernel with
+ * rsqrtf and contraction, the HIP kernels) is only defined up to ~1 ulp per term, i.e. up to 2^-24 kappa_i
+ * relative to |a_i| (tests/test_spatial_hash_gpu.py states its per-body bound with it). */
+static int hash_forces_grid(size_t n, size_t n_t, const float* x, const float* y, const float* z, const float* m,
+                            float* ax, float* ay, float* az, float G, float eps2, float cell_size, float cutoff,
+                            const float bmin[3], const int dims[3], double* gold, double* abs_sum) {
   long long cells = (long long)dims[0] * dims[1] * dims[2];
   if (cells > 100000000LL) return -1; /* force_spatial_hash.cu:252-254 */
   int* cell_of = (int*)malloc(n * sizeof(int));
@@ -402,6 +406,7 @@ ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float
     int cy = clampi((int)floorf((yi - bmin[1]) / cell_size), 0, dims[1] - 1);
     int cz = clampi((int)floorf((zi - bmin[2]) / cell_size), 0, dims[2] - 1);
     double a0 = 0, a1 = 0, a2 = 0;
+    double g0 = 0, g1 = 0, g2 = 0, sabs = 0;
     for (int dz = -1; dz <= 1; dz++)
       for (int dy = -1; dy <= 1; dy++)
         for (int dx = -1; dx <= 1; dx++) {
@@ -418,16 +423,44 @@ ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float
               float dist2 = r2 + eps2;
               float inv = 1.0f / sqrtf(dist2);
               float f = G * m[j] * (inv * inv * inv);
-              a0 += (double)(f * ddx);
-              a1 += (double)(f * ddy);
-              a2 += (double)(f * ddz);
+              float t0 = f * ddx, t1 = f * ddy, t2 = f * ddz;
+              a0 += (double)t0;
+              a1 += (double)t1;
+              a2 += (double)t2;
+              if (gold || abs_sum) {
+                double ex = (double)x[j] - (double)xi, ey = (double)y[j] - (double)yi, ez = (double)z[j] - (double)zi;
+                double q = ex * ex + ey * ey + ez * ez + (double)eps2;
+                double fg = (double)G * (double)m[j] / (q * sqrt(q));
+                g0 += fg * ex; g1 += fg * ey; g2 += fg * ez;
+                sabs += sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
+              }
             }
           }
         }
     ax[i] = (float)a0; ay[i] = (float)a1; az[i] = (float)a2;
+    if (gold) { gold[3 * i] = g0; gold[3 * i + 1] = g1; gold[3 * i + 2] = g2; }
+    if (abs_sum) abs_sum[i] = sabs;
   }
   free(cell_of); free(start); free(order);
   return 0;
+}
+
+ORACLE_API int oracle_spatial_hash_forces_grid(size_t n, size_t n_t, const float* x, const float* y,
+                                               const float* z, const float* m, float* ax, float* ay,
+                                               float* az, float G, float eps2, float cell_size,
+                                               float cutoff, const float bmin[3], const int dims[3]) {
+  return hash_forces_grid(n, n_t, x, y, z, m, ax, ay, az, G, eps2, cell_size, cutoff, bmin, dims, NULL, NULL);
+}
+
+/* the same forces plus, per body, the fp64 sum over the same pair set and the sum of the term magnitudes */
+ORACLE_API int oracle_spatial_hash_forces_cond(size_t n, const float* x, const float* y, const float* z,
+                                               const float* m, float* ax, float* ay, float* az, float G,
+                                               float eps2, float cell_size, float cutoff, double* gold,
+                                               double* abs_sum) {
+  float bmin[3], bmax[3];
+  int dims[3];
+  oracle_hash_grid(n, x, y, z, cell_size, bmin, bmax, dims);
+  return hash_forces_grid(n, n, x, y, z, m, ax, ay, az, G, eps2, cell_size, cutoff, bmin, dims, gold, abs_sum);
 }
 
 ORACLE_API int oracle_spatial_hash_forces(size_t n, const float* x, const float* y,

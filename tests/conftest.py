@@ -32,3 +32,19 @@ def ctx(nb):
         pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
     torch.cuda.set_device(0)
     return nb.default_context(0)
+
+
+@pytest.fixture(autouse=True)
+def _restore_session_context(request):
+    """The context of the -m gpu tests is session-wide (nb.default_context is cached): a test that changes its
+    determinism mode or its tuning overrides must not leak that into the tests after it.  Snapshot before,
+    restore after (the tuning overrides have no getter: they are reset to automatic)."""
+    if "ctx" not in request.fixturenames:
+        yield
+        return
+    c = request.getfixturevalue("ctx")
+    mode = c.directInfo()["deterministic_mode"]
+    yield
+    c.tuning()
+    if c.directInfo()["deterministic_mode"] != mode:
+        c.deterministic(mode)

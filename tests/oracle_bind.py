@@ -52,6 +52,10 @@ class Oracle:
         L.oracle_spatial_hash_forces_grid.argtypes = [C.c_size_t, C.c_size_t, _f, _f, _f, _f, _f, _f, _f,
                                                       C.c_float, C.c_float, C.c_float, C.c_float, _f3, _i3]
         L.oracle_spatial_hash_forces_grid.restype = C.c_int
+        _d = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        L.oracle_spatial_hash_forces_cond.argtypes = [C.c_size_t, _f, _f, _f, _f, _f, _f, _f, C.c_float, C.c_float,
+                                                      C.c_float, C.c_float, _d, _d]
+        L.oracle_spatial_hash_forces_cond.restype = C.c_int
         L.oracle_direct_cutoff_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, C.c_size_t, _i64, _f, _f,
                                                   _f, C.c_float, C.c_float, C.c_float]
         L.oracle_barnes_hut_forces.argtypes = [C.c_size_t, _f, _f, _f, _f, C.c_size_t, _i64, _f, _f, _f,
@@ -135,6 +139,17 @@ class Oracle:
         if rc:
             raise RuntimeError("grid too large")
         return ax, ay, az
+
+    def spatial_hash_forces_cond(self, x, y, z, m, G, eps2, cell, cutoff):
+        """(acc [n,3] float32, gold [n,3] float64, kappa [n]): the oracle's forces, the fp64 sum over the same pair
+        set, and the condition number sum_j |t_ij| / |a_i| of every body's sum."""
+        ax, ay, az = (np.empty(x.size, np.float32) for _ in range(3))
+        gold, sabs = np.empty((x.size, 3), np.float64), np.empty(x.size, np.float64)
+        if self.L.oracle_spatial_hash_forces_cond(x.size, x, y, z, m, ax, ay, az, G, eps2, cell, cutoff, gold, sabs):
+            raise RuntimeError("grid too large")
+        acc = np.stack([ax, ay, az], 1)
+        kappa = sabs / np.maximum(np.linalg.norm(acc.astype(np.float64), axis=1), 1e-300)
+        return acc, gold, kappa
 
     def spatial_hash_forces_grid(self, x, y, z, m, n_t, G, eps2, cell, cutoff, bmin, dims):
         ax, ay, az = (np.empty(n_t, np.float32) for _ in range(3))

@@ -215,7 +215,10 @@ def test_leaf_max_variant(nb, oracle, ctx):
     assert tree.getNodeCount() == r[4]
 
 
-# BASELINE config 4 at full size (N = 1,048,576 two-galaxy, theta = 0.5): size-independent checks
+# BASELINE config 4 at full size (N = 1,048,576 two-galaxy, theta = 0.5): EVERY body against the oracle's walk of
+# the same tree (~1-2 s on the box), on the default pair walk, before and with the cost-ordered schedule (the
+# second and third walks after a build are scheduled from the node visits the previous one recorded); node
+# count and root mass equal; then the size-independent checks
 def test_full_size_two_galaxies(nb, oracle, ctx):
     n = 1 << 20
     ic = nb.ic.two_galaxies(n, seed=42)
@@ -230,6 +233,19 @@ def test_full_size_two_galaxies(nb, oracle, ctx):
     st = tree.stats()
     assert abs(st["root_mass"] - 1.0) < 1e-3 and tree.verifyMassConservation(h)   # :511-519
     assert n < st["node_count"] < 3 * n
+    bx, by, bz, root_mass, nodes = oracle.barnes_hut_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"],
+                                                           np.arange(n), 1.0, float(np.float32(0.1) ** 2), 0.5)
+    tref = np.stack([bx, by, bz], 1)
+    assert st["node_count"] == nodes and abs(st["root_mass"] - root_mass) < 1e-6 * root_mass
+    for walk in range(3):
+        if walk:
+            calc.computeForces(d)   # scheduled longest-first from the previous walk's visit counts
+        e = rel_err(acc_of(d), tref)
+        msg = (f"N = {n} walk {walk}: all {n} bodies, max {e.max():.3e}, p99.99 {np.quantile(e, 0.9999):.3e}, "
+               f"median {np.median(e):.3e}, above 1e-5: {(e > TOL).sum()}")
+        print(msg)
+        assert e.max() < TOL, msg
+        assert np.array_equal(acc_of(d), a)  # the schedule does not change a bit
     # sampled bodies against the exact sum (oracle, fp64-accumulated): the theta = 0.5 contract
     idx = np.linspace(0, n - 1, 96).astype(np.int64)
     ref = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx,
@@ -239,8 +255,6 @@ def test_full_size_two_galaxies(nb, oracle, ctx):
     # theta = 0 on the same tree is the exact sum
     tree.computeForces(d, 0.0, 1.0, 0.1)
     assert rel_err(acc_of(d)[idx], ref).max() < TOL
-    calc.computeForces(d)
-    assert np.array_equal(acc_of(d), a)  # reproducible
 
 
 # the split walk (few bodies: K replicas share each wave's walk) against the plain walk: same

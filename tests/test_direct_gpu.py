@@ -400,13 +400,16 @@ def test_deterministic_symmetric_kernel(nb, oracle, ctx, n, tpl, equal_mass):
     eps2 = 1e-6
     try:
         ctx.tuning(3 if tpl else -1, tpl, 0)
+        ctx.deterministic(False)
         plain = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
-        ctx.deterministic(True)
+        assert ctx.directInfo()["last_kernel"] == 1          # symmetric kernel with fp64 atomics
+        ctx.deterministic(2)                                  # slot planes REQUIRED: no silent switch
         a = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
+        assert ctx.directInfo()["last_kernel"] == 2
         b = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
         c = nb.direct_forces_packed(ctx, p, p, 1.0, eps2)
     finally:
-        ctx.deterministic(False)
+        ctx.deterministic(True)
         ctx.tuning()
     assert torch.equal(a, b) and torch.equal(a, c)  # bit for bit, launch after launch
     # (the two forms may run with different bodies per lane -- general masses: 12 with slots, 16 with atomics --
@@ -443,9 +446,105 @@ def test_deterministic_direct_save_load_continue(nb, ctx):
                 integ.integrate(d, fc, 1e-3)
         return np.stack([getattr(d, k).cpu().numpy() for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z")])
 
-    try:
-        ctx.deterministic(True)
-        whole, resumed = run(4), run(2)
-    finally:
-        ctx.deterministic(False)
+    assert ctx.directInfo()["deterministic_mode"] == 1   # the documented default: nothing to switch on
+    whole, resumed = run(4), run(2)
+    assert ctx.directInfo()["last_kernel"] == 2
     assert np.array_equal(whole, resumed)
+
+
+# the two-set (shard pair) kernel follows the same switch: slot planes -> bitwise reproducible, same
+# values as the atomic form to rounding; mode 2 never switches silently
+@pytest.mark.parametrize("na,nb_,masses", [(55001, 55002, "equal"), (55001, 55002, "random"), (20000, 9000, "random"),
+                                            (4000, 5000, "equal")])
+def test_deterministic_pair_kernel(nb, ctx, na, nb_, masses):
+    n = na + nb_
+    ic = nb.ic.plummer(n, seed=79)
+    if masses == "random":
+        ic["mass"] = (ic["mass"] * np.random.default_rng(6).uniform(0.5, 2.0, n)).astype(np.float32)
+    p = packed(ic)
+    a, b = p[:na].contiguous(), p[na:].contiguous()
+
+    def run():
+        acc_a = torch.full((na, 4), 3.0, device="cuda")
+        acc_b = torch.full((nb_, 4), 3.0, device="cuda")
+        nb.direct_forces_pair_packed(ctx, a, b, 1.0, 1e-6, acc_a, acc_b)
+        return acc_a, acc_b
+    try:
+        ctx.deterministic(False)
+        pa, pb = run()
+        assert ctx.directInfo()["last_kernel"] == 1
+        ctx.deterministic(2)
+        runs = [run() for _ in range(3)]
+        assert ctx.directInfo()["last_kernel"] == 2
+    finally:
+        ctx.deterministic(True)
+    for ra, rb in runs[1:]:
+        assert torch.equal(ra, runs[0][0]) and torch.equal(rb, runs[0][1])
+    assert rel_err(runs[0][0].cpu().numpy()[:, :3], pa.cpu().numpy()[:, :3]).max() < 5e-6
+    assert rel_err(runs[0][1].cpu().numpy()[:, :3], pb.cpu().numpy()[:, :3]).max() < 5e-6
+    try:
+        ctx.tuning(1, 4, 0)  # the one-sided kernel (verified against the oracle above) as the reference
+        oa = nb.direct_forces_packed(ctx, a, b, 1.0, 1e-6)
+        ob = nb.direct_forces_packed(ctx, b, a, 1.0, 1e-6)
+    finally:
+        ctx.tuning()
+    assert rel_err(runs[0][0].cpu().numpy()[:, :3], oa.cpu().numpy()[:, :3]).max() < TOL
+    assert rel_err(runs[0][1].cpu().numpy()[:, :3], ob.cpu().numpy()[:, :3]).max() < TOL
+
+
+# nbody_hip_direct_info / the memory policy of the slot planes: the plan is visible before the call, the mode
+# that ran after it; a workspace four times too large is given back; mode 0 releases the planes; mode 2 fails
+# loudly where mode 1 falls back
+def test_direct_info_and_workspace_policy(nb, ctx):
+    big, small = 300000, 20000
+    pb_, ps_ = packed(nb.ic.plummer(big, seed=1)), packed(nb.ic.plummer(small, seed=2))
+    plan = ctx.directInfo(big, 1e-6)
+    assert plan["deterministic_mode"] == 1 and plan["kernel"] == 2 and plan["kernel_name"] == "symmetric+slots"
+    assert plan["bodies_per_lane_equal"] == 16 and plan["bodies_per_lane_general"] == 12
+    nb.direct_forces_packed(ctx, pb_, pb_, 1.0, 1e-6)
+    held = ctx.directInfo()["workspace_bytes_held"]
+    assert held >= plan["workspace_bytes_needed"] > 100 << 20
+    assert ctx.directInfo()["last_kernel"] == 2
+    nb.direct_forces_packed(ctx, ps_, ps_, 1.0, 1e-6)      # a much smaller problem follows: the planes go back
+    assert ctx.directInfo()["workspace_bytes_held"] < held // 4
+    nb.direct_forces_packed(ctx, pb_, pb_, 1.0, 1e-6)
+    try:
+        ctx.deterministic(False)                             # switching the planes off frees them
+        assert ctx.directInfo()["workspace_bytes_held"] == 0
+        assert ctx.directInfo(big, 1e-6)["kernel"] == 1
+    finally:
+        ctx.deterministic(True)
+    # one-sided kernel below 12,288 bodies and for tiny softening
+    assert ctx.directInfo(5000, 1e-6)["kernel"] == 0 and ctx.directInfo(big, 0.0)["kernel"] == 0
+    # beyond the 24 GiB budget: mode 1 reports (and takes) the atomic form, mode 2 refuses
+    huge = ctx.directInfo(6_000_000, 1e-6)
+    assert huge["kernel"] == 1 and huge["slot_bytes_wanted"] > 24 << 30
+    with pytest.raises(nb.ValidationException):
+        ctx.deterministic(3)
+    # a tight budget (a shared GPU): mode 1 takes the atomic form and says so, mode 2 refuses the call
+    try:
+        ctx.slotBudget(8 << 20)
+        assert ctx.directInfo(big, 1e-6)["kernel"] == 1
+        ref = nb.direct_forces_packed(ctx, pb_, pb_, 1.0, 1e-6)
+        assert ctx.directInfo()["last_kernel"] == 1
+        ctx.deterministic(2)
+        with pytest.raises(nb.ResourceException, match="slot planes"):
+            nb.direct_forces_packed(ctx, pb_, pb_, 1.0, 1e-6)
+        with pytest.raises(nb.ResourceException, match="slot planes"):
+            nb.direct_forces_pair_packed(ctx, pb_[:150000].contiguous(), pb_[150000:].contiguous(), 1.0, 1e-6,
+                                         torch.empty((150000, 4), device="cuda"), torch.empty((150000, 4), device="cuda"))
+        ctx.slotBudget(0)
+        det = nb.direct_forces_packed(ctx, pb_, pb_, 1.0, 1e-6)
+        assert ctx.directInfo()["last_kernel"] == 2
+        assert rel_err(det.cpu().numpy()[:, :3], ref.cpu().numpy()[:, :3]).max() < 5e-6
+    finally:
+        ctx.slotBudget(0)
+        ctx.deterministic(True)
+
+
+# at the end of this file the session-wide context is in the documented default mode (the fixture in conftest.py
+# restores it after every test; the tests after this file rely on it)
+def test_default_context_is_deterministic_at_the_end(nb, ctx):
+    info = ctx.directInfo(1 << 20, 1e-6)
+    assert info["deterministic_mode"] == 1 and info["kernel"] == 2
+    assert nb.default_context(0) is ctx

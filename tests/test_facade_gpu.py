@@ -62,6 +62,41 @@ def test_reference_example_force_methods(tmp_path):
         assert name in out
 
 
+# The reference's OWN CPU force loop (computeReferenceForces, examples/example_force_methods.cpp:34-67), compiled
+# from /root/reference and run here: its forces equal the committed fixture (tests/golden/direct_refloop.npz, made
+# by the same driver) and the oracle's mode 0 BIT FOR BIT, and the HIP Direct path agrees with it within the
+# bound of an fp32 running sum over N terms (2e-5; the fp64-accumulated oracle is the 1e-5 bar elsewhere).
+@pytest.mark.parametrize("name", ["plummer4096", "sphere3000"])
+def test_reference_cpu_force_loop_pins_oracle_and_hip(tmp_path, name):
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_refloop_fixture as mk
+    import nbody_amd as nb
+    import oracle_bind
+    from gpu_util import acc_of, rel_err, to_device
+    _need("ref_force_loop_driver")
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "direct_refloop.npz"))
+    ic, G, eps = next((ic, G, eps) for nm, ic, G, eps in mk.cases() if nm == name)
+    live, log = mk.run_reference_loop(ic, G, eps, str(tmp_path))
+    assert f"bodies {ic['pos_x'].size}" in log
+    assert np.array_equal(live, fix[f"{name}_acc_refloop"])          # the committed fixture is what the reference computes
+    o = oracle_bind.load()
+    e32 = np.float32(eps)
+    a0 = np.stack(o.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], G, float(e32 * e32), 0), 1)
+    assert np.array_equal(a0, live)                                   # oracle mode 0 == the reference's loop
+    d, _ = to_device(nb, {k: np.ascontiguousarray(v, np.float32) for k, v in ic.items()})
+    calc = nb.DirectForceCalculator()
+    calc.setGravitationalConstant(G)
+    calc.setSofteningParameter(eps)
+    calc.computeForces(d)
+    err = rel_err(acc_of(d), live)
+    assert err.max() < 2e-5 and np.median(err) < 2e-6, err.max()
+
+
 # A caller compiled against the REFERENCE's headers that constructs BarnesHutTree / SpatialHashGrid
 # itself (as ref: tests/test_barnes_hut.cpp:29,54,118 and tests/test_spatial_hash.cpp:29,110 do) and
 # a user ForceCalculator subclass through Integrator::integrate.  The _asan build has the driver AND

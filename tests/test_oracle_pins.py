@@ -226,3 +226,31 @@ def test_oracle_reproduces_spatial_hash_golden(oracle):
     assert np.allclose(g["acc_c1"], g["acc_cutoff_direct"], rtol=1e-5, atol=1e-6)
     lo, hi, dims = oracle.hash_grid(g["pos_x"], g["pos_y"], g["pos_z"], float(g["cell"]))
     assert list(dims) == list(g["dims"])
+
+
+# The reference's OWN CPU all-pairs loop -- computeReferenceForces, examples/example_force_methods.cpp:34-67, the
+# only CPU force loop the reference holds -- compiled from /root/reference (oracle/Makefile.ref ->
+# oracle/_ref/ref_force_loop_driver) and run on two committed body sets by tests/golden/make_refloop_fixture.py;
+# its output is tests/golden/direct_refloop.npz.  The oracle's arithmetic mode 0 is that loop restated: it must
+# reproduce the reference-generated accelerations BIT FOR BIT (equal and general masses, G = 1 and G != 1), and
+# the parity oracle (mode 1: the same fp32 terms, fp64 accumulation) and fp64 gold must agree with it to the
+# rounding of a 4,096-term fp32 running sum.  This is what pins BASELINE config 1's fixture to the reference.
+@pytest.mark.parametrize("name", ["plummer4096", "sphere3000"])
+def test_direct_oracle_equals_reference_cpu_loop(oracle, name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direct_refloop.npz"))
+    x, y, z, m = (g[f"{name}_{k}"] for k in ("pos_x", "pos_y", "pos_z", "mass"))
+    G, eps = float(g[f"{name}_G"]), np.float32(g[f"{name}_eps"])
+    eps2 = float(eps * eps)   # the loop forms eps * eps in fp32 (:55)
+    ref = g[f"{name}_acc_refloop"]
+    assert ref.shape == (x.size, 3) and np.all(np.isfinite(ref))
+    a0 = np.stack(oracle.direct_forces(x, y, z, m, G, eps2, 0), 1)
+    assert np.array_equal(a0, ref), "oracle mode 0 is not the reference's CPU loop any more"
+    for mode in (1, 2):
+        a = np.stack(oracle.direct_forces(x, y, z, m, G, eps2, mode), 1).astype(np.float64)
+        e = np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert e.max() < 2e-5 and np.median(e) < 2e-6, (mode, e.max())
+    if name == "plummer4096":  # the committed config-1 golden vectors are these very numbers
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plummer4096_direct.npz"))
+        assert np.array_equal(gold["acc_f32seq"], ref)
+        assert np.array_equal(gold["pos_x"], x) and np.array_equal(gold["mass"], m)

@@ -10,6 +10,7 @@ from gpu_util import acc_of, rel_err, to_device
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+KERNELS = (1, 2, 3, 4)   # force kernels of the grid (nbody_hip_grid_tuning): cell runs; one wave per cell with 1 / 2 / 4 bodies per lane
 
 
 # tests/test_spatial_hash.cpp:15-36 GridConstruction + :53-83 ComputeForces
@@ -112,7 +113,7 @@ def test_forces_match_oracle(nb, oracle, ctx, n, box, cell, cutoff, eps, tol):
     # 2 / 3 / 4 = one wave per cell with 1 / 2 / 4 bodies per lane; the dense case has windows longer than
     # a wave's LDS batch and cells with more bodies than one chunk of target slots)
     g = calc.getGrid()
-    for kern in (1, 2, 3, 4):
+    for kern in KERNELS:
         g.tuning(kern)
         calc.computeForces(d)
         ak = acc_of(d)
@@ -300,7 +301,40 @@ def test_packed_slabs_equal_whole(nb, oracle, ctx, cutoff):
     assert np.allclose(vel[:, 1], d.vel_y.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
-# BASELINE config 5 at full size on one GPU (N = 4,194,304, 16 bodies per unit volume)
+# The per-body bound of the whole-population comparisons.  A body's acceleration is a sum of fp32 terms that may
+# nearly cancel (uniform medium): kappa_i = sum_j |t_ij| / |a_i| is the condition number of that sum, computed by
+# the oracle.  Any fp32 evaluation of the terms -- the oracle's 1/sqrtf, the reference kernel's rsqrtf under nvcc's
+# contraction, v_rsq_f32 here -- is defined up to ~1 ulp per term, so two of them can only be expected to agree
+# to about 2^-24 kappa_i relative to |a_i|: measured with EXACT accumulation of rsq-rounded terms against the oracle
+# on the 400 most-cancelling bodies of config 5 (kappa 200-700): max 0.90 x 2^-24 kappa = 1.4e-5, and the oracle
+# itself is up to 1.6e-5 from the fp64 sum there (profiles/r03_hash_tail_analysis.txt, tools/hash_tail_experiment.py).
+# So: EVERY body must meet  err_i <= max(1e-5, 2^-24 kappa_i)  -- the strict 1e-5 of SURVEY section 7 for every
+# body with kappa_i <= 168 (99.99 % of config 5), and one ulp per term of backward error beyond.
+U = 2.0 ** -24
+
+
+def assert_every_body(tag, a, ref, kappa, gold=None):
+    nz = np.linalg.norm(ref, axis=1) > 0
+    assert np.all(a[~nz] == 0), tag
+    e = rel_err(a[nz], ref[nz])
+    k = kappa[nz]
+    bound = np.maximum(TOL, U * k)
+    worst = int(np.argmax(e / bound))
+    msg = (f"{tag}: {nz.sum()} bodies, max {e.max():.3e}, p99.99 {np.quantile(e, 0.9999):.3e}, median {np.median(e):.3e}, "
+           f"above 1e-5: {(e > TOL).sum()} (all with kappa > {k[e > TOL].min() if (e > TOL).any() else 0:.0f}), "
+           f"max err / (2^-24 kappa): {(e / (U * k)).max():.2f}, worst vs bound: err {e[worst]:.3e} kappa {k[worst]:.0f}")
+    print(msg)
+    assert np.all(e <= bound), msg
+    assert np.all(e[k <= 168] < TOL), msg          # the strict per-body metric wherever fp32 terms can carry it
+    if gold is not None:                            # and no farther from the fp64 sum than one ulp per term either
+        eg = rel_err(a[nz], gold[nz])
+        assert np.all(eg <= np.maximum(TOL, 1.5 * U * k)), (tag, eg.max())
+    return msg
+
+
+# BASELINE config 5 at full size on one GPU (N = 4,194,304, 16 bodies per unit volume): EVERY body against the
+# oracle's 27-cell search (oracle.spatial_hash_forces_cond: ~2 s on the box), for the default kernel and for each
+# force kernel of the grid
 def test_full_size_uniform_box(nb, oracle, ctx):
     n, half = 4194304, 32.0
     ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
@@ -312,38 +346,58 @@ def test_full_size_uniform_box(nb, oracle, ctx):
     assert np.all(np.isfinite(a))
     g = calc.getGrid()
     assert g.getGridDims() == (66, 66, 66) or g.getGridDims() == (65, 65, 65)
+    ref, gold, kappa = oracle.spatial_hash_forces_cond(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                                       float(np.float32(0.01) ** 2), 1.0, 1.0)
+    assert_every_body(f"N = {n} default kernel", a, ref, kappa, gold)
+    # ... and equals the direct sum restricted to the cutoff on a sample (the 27-cell search is complete here)
     idx = np.linspace(0, n - 1, 1024).astype(np.int64)
     dc = np.stack(oracle.direct_cutoff_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx, 1.0,
                                               float(np.float32(0.01) ** 2), 1.0), 1)
-    e = rel_err(a[idx], dc)
-    print(f"N = {n}: {idx.size} oracle bodies, max rel err {e.max():.3e}, median {np.median(e):.3e}")
-    assert e.max() < TOL
-    # every force kernel of the grid gives the reference's 27-cell result
+    assert np.array_equal(dc, ref[idx])
+    # every force kernel of the grid gives the reference's 27-cell result, on every body
     g.build(d)
-    for kern in (1, 2, 3, 4):
+    for kern in KERNELS:
         g.tuning(kern)
         g.computeForces(d, 1.0, 1.0, 0.01)
-        ek = rel_err(acc_of(d)[idx], dc)
-        assert ek.max() < TOL, (kern, ek.max())
+        assert_every_body(f"N = {n} kernel {kern}", acc_of(d), ref, kappa)
     g.tuning(0)
     # short-range forces of a uniform medium cancel on average: the mean is far below the rms
     assert np.abs(a.mean(0)).max() < 0.02 * a.std(0).min()
 
 
-# BASELINE config 5 in small, against the committed golden vectors (tests/golden/make_golden.py)
-def test_golden_uniform_4096(nb, ctx):
+# the same box with cutoff 2 > cell (the reference's default ratio: its 27-cell search misses pairs, reproduced) and
+# a dense one (107 bodies per cell: windows longer than a wave's LDS batch), every body
+@pytest.mark.parametrize("n,half,cutoff", [(4194304, 32.0, 2.0), (2000000, 13.0, 1.0)])
+def test_full_size_other_regimes(nb, oracle, ctx, n, half, cutoff):
+    ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
+    d, _ = to_device(nb, ic)
+    g = nb.SpatialHashGrid(n, 1.0)
+    g.build(d)
+    ref, gold, kappa = oracle.spatial_hash_forces_cond(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                                       float(np.float32(0.01) ** 2), 1.0, cutoff)
+    for kern in (0, 1):
+        g.tuning(kern)
+        g.computeForces(d, cutoff, 1.0, 0.01)
+        assert_every_body(f"N = {n} cutoff {cutoff} kernel {kern}", acc_of(d), ref, kappa, gold if kern == 0 else None)
+    g.tuning(0)
+
+
+# BASELINE config 5 in small, against the committed golden vectors (tests/golden/make_golden.py): per body
+def test_golden_uniform_4096(nb, oracle, ctx):
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "uniform4096_spatial_hash.npz"))
     ic = {k: g[k] for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")}
     d, _ = to_device(nb, ic)
+    eps = np.float32(g["eps"])
     for name, cutoff in (("acc_c1", 1.0), ("acc_c2", 2.0)):
         calc = nb.SpatialHashCalculator(float(g["cell"]), cutoff)
         calc.setGravitationalConstant(float(g["G"]))
         calc.setSofteningParameter(float(g["eps"]))
         calc.computeForces(d)
-        ref = g[name].astype(np.float64)
-        scale = np.sqrt((ref ** 2).sum(1).mean())
-        assert np.abs(acc_of(d) - ref).max() < 1e-5 * max(scale, np.abs(ref).max() * 0.1), name
+        ref, _, kappa = oracle.spatial_hash_forces_cond(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], float(g["G"]),
+                                                        float(eps * eps), float(g["cell"]), cutoff)
+        assert np.array_equal(ref, g[name])   # the committed vectors are what the oracle computes
+        assert_every_body(f"golden {name}", acc_of(d), g[name], kappa)
         assert list(calc.getGrid().getGridDims()) == list(g["dims"])
     cs, ce, pc, si = calc.getGrid().copyCellDataToHost()
     assert np.array_equal(pc, g["cell_of"])   # every body in the cell the oracle puts it in
