@@ -18,6 +18,8 @@ from .api import (BarnesHutCalculator, BarnesHutTree, Context, StepGraph, Direct
 from .system import (MAX_PARTICLE_COUNT, NBODY_MAGIC, NBODY_VERSION, ParticleSystem,  # noqa: F401,E402
                      Serializer, SimulationState)
 from . import observability  # noqa: F401,E402
+from . import sharded  # noqa: F401,E402
+from ._lib import CommException  # noqa: F401,E402
 
 
 def __getattr__(name):

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnbody_hip.so")
 
 # status codes (include/nbody_hip.h: nbody_hip_status)
-OK, ERR_VALIDATION, ERR_DEVICE, ERR_RESOURCE, ERR_STATE = 0, -1, -2, -3, -4
+OK, ERR_VALIDATION, ERR_DEVICE, ERR_RESOURCE, ERR_STATE, ERR_COMM = 0, -1, -2, -3, -4, -5
 
 
 class NBodyError(RuntimeError):
@@ -35,8 +35,12 @@ class StateException(NBodyError):
     """call-sequence error (null handle / missing arrays)"""
 
 
+class CommException(NBodyError):
+    """RCCL error / RCCL not loadable (include/nbody_hip_comm.h)"""
+
+
 _EXC = {ERR_VALIDATION: ValidationException, ERR_DEVICE: DeviceException,
-        ERR_RESOURCE: ResourceException, ERR_STATE: StateException}
+        ERR_RESOURCE: ResourceException, ERR_STATE: StateException, ERR_COMM: CommException}
 
 
 class ParticleDataStruct(C.Structure):
@@ -140,6 +144,25 @@ PROTOTYPES = {
     "nbody_hip_direct_slot_budget": (C.c_int, [_P, C.c_ulonglong]),
     "nbody_hip_direct_info": (C.c_int, [_P, C.c_size_t, C.c_float, _P]),
     "nbody_hip_direct_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    # include/nbody_hip_comm.h
+    "nbody_hip_comm_init_all": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "nbody_hip_comm_unique_id": (C.c_int, [_P]),
+    "nbody_hip_comm_init_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "nbody_hip_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
+    "nbody_hip_comm_destroy": (C.c_int, [_P]),
+    "nbody_hip_shard_bounds": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_size_t)]),
+    "nbody_hip_pair_schedule": (C.c_int, [C.c_int, C.c_int, C.c_size_t, _P, C.c_int]),
+    "nbody_hip_sharded_direct_create": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_float, C.POINTER(_P)]),
+    "nbody_hip_sharded_direct_destroy": (C.c_int, [_P]),
+    "nbody_hip_sharded_direct_set_state": (C.c_int, [_P] * 8),
+    "nbody_hip_sharded_direct_forces": (C.c_int, [_P]),
+    "nbody_hip_sharded_direct_step": (C.c_int, [_P, C.c_float, C.c_int]),
+    "nbody_hip_sharded_direct_time_steps": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nbody_hip_sharded_direct_synchronize": (C.c_int, [_P]),
+    "nbody_hip_sharded_direct_get_state": (C.c_int, [_P] * 10 + [C.c_int]),
+    "nbody_hip_sharded_direct_energies": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nbody_hip_sharded_direct_compute_forces": (C.c_int, [_P, _PD]),
 }
 
 _lib = None

@@ -35,6 +35,8 @@ inline constexpr int3 make_int3(int x, int y, int z) { return {x, y, z}; }
 struct nbody_hip_ctx;
 struct nbody_hip_tree;
 struct nbody_hip_grid;
+struct nbody_hip_comm;
+struct nbody_hip_sharded_direct;
 
 namespace nbody {
 
@@ -214,6 +216,28 @@ public:
   int getBlockSize() const noexcept { return block_size_; }
 private:
   int block_size_;
+};
+
+// MI355X-native addition (no reference counterpart; the reference is single-GPU): Direct N^2 shared by `ndev`
+// GPUs of one node behind the SAME plugin interface -- computeForces(ParticleData*) on a whole-system
+// ParticleData that lives on device 0; positions go out and accelerations come back as peer copies over
+// xGMI (include/nbody_hip_comm.h: nbody_hip_comm_init_all + nbody_hip_sharded_direct_compute_forces).
+// Drops into Integrator::integrate / ParticleSystem like any user-defined ForceCalculator.
+class ShardedDirectCalculator : public ForceCalculator {
+public:
+  // devices: the GPUs to share the work (empty = all visible devices); rccl: RCCL collectives instead of peer copies
+  explicit ShardedDirectCalculator(std::vector<int> devices = {}, bool rccl = false);
+  ~ShardedDirectCalculator() override;
+  void computeForces(ParticleData* d_particles) override;
+  ForceMethod getMethod() const noexcept override { return ForceMethod::DIRECT_N2; }
+  int getDeviceCount() const noexcept { return static_cast<int>(devices_.size()); }
+private:
+  std::vector<int> devices_;
+  bool rccl_;
+  ::nbody_hip_comm* comm_ = nullptr;
+  ::nbody_hip_sharded_direct* sys_ = nullptr;
+  size_t count_ = 0;
+  float built_G_ = 0.f, built_eps_ = -1.f;
 };
 
 class BarnesHutCalculator : public ForceCalculator {

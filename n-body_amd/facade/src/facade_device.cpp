@@ -8,6 +8,7 @@
 
 #include "nbody_facade.hpp"
 #include "nbody_hip.h"
+#include "nbody_hip_comm.h"
 
 namespace nbody {
 
@@ -157,6 +158,35 @@ void launchDirectForceKernel(ParticleData* d, float G, float eps2, int block_siz
 DirectForceCalculator::DirectForceCalculator(int block_size) : block_size_(block_size) {}
 void DirectForceCalculator::computeForces(ParticleData* d) {
   launchDirectForceKernel(d, G_, softening_eps2_, block_size_);
+}
+
+// ---- Direct, shared by the GPUs of one node (MI355X-native addition) -------------------------------
+ShardedDirectCalculator::ShardedDirectCalculator(std::vector<int> devices, bool rccl)
+    : devices_(std::move(devices)), rccl_(rccl) {
+  if (devices_.empty()) {
+    const int n = nbody_hip_device_count();
+    for (int k = 0; k < n; k++) devices_.push_back(k);
+  }
+  NBODY_CHECK(nbody_hip_comm_init_all(static_cast<int>(devices_.size()), devices_.data(),
+                                      rccl_ ? NBODY_HIP_TRANSPORT_RCCL : NBODY_HIP_TRANSPORT_P2P, &comm_));
+}
+ShardedDirectCalculator::~ShardedDirectCalculator() {
+  nbody_hip_sharded_direct_destroy(sys_);
+  nbody_hip_comm_destroy(comm_);
+}
+void ShardedDirectCalculator::computeForces(ParticleData* d) {
+  const float eps = softening_eps_;  // the library squares it in fp32 exactly as setSofteningParameter does
+  // sized from the count seen (like the tree / grid calculators, force_barnes_hut.cu:527-529); rebuilt when the
+  // body count or a parameter changes (the setters are plain stores read at the next call)
+  if (!sys_ || count_ != d->count || built_G_ != G_ || built_eps_ != eps) {
+    nbody_hip_sharded_direct_destroy(sys_);
+    sys_ = nullptr;
+    NBODY_CHECK(nbody_hip_sharded_direct_create(comm_, d->count, G_, eps, &sys_));
+    count_ = d->count;
+    built_G_ = G_;
+    built_eps_ = eps;
+  }
+  NBODY_CHECK(nbody_hip_sharded_direct_compute_forces(sys_, raw(d)));
 }
 
 Vec3 computeGravitationalForceCPU(const Vec3& p1, const Vec3& p2, float /*m1*/, float m2, float G, float eps) {

@@ -235,6 +235,48 @@ int main() {
          try { ParticleData d; d.count = 4; DirectForceCalculator(256).computeForces(&d); } catch (const CudaException&) { threw = true; }
          CHECK(threw);
        }},
+      // MI355X-native addition: the SAME plugin interface, force work shared by several ranks (here: virtual ranks
+      // on device 0; on a node: ShardedDirectCalculator() = all GPUs).  A reference-style caller -- Integrator::
+      // integrate with a ForceCalculator* -- runs BASELINE config 3's step without knowing about the ranks.
+      {"ShardedDirectCalculator (4 ranks, plugin interface) == DirectForceCalculator through Integrator::integrate", [] {
+         const size_t n = 30000;
+         ParticleData d1, d2, h1, h2;
+         fill_sphere(d1, h1, n, 5.0f);
+         fill_sphere(d2, h2, n, 5.0f);
+         DirectForceCalculator one(256);
+         ShardedDirectCalculator many(std::vector<int>{0, 0, 0, 0});
+         CHECK(many.getDeviceCount() == 4 && many.getMethod() == ForceMethod::DIRECT_N2);
+         for (ForceCalculator* c : {static_cast<ForceCalculator*>(&one), static_cast<ForceCalculator*>(&many)}) {
+           c->setGravitationalConstant(1.5f);
+           c->setSofteningParameter(0.05f);
+         }
+         one.computeForces(&d1);
+         many.computeForces(&d2);
+         Integrator integ(256);
+         for (int s = 0; s < 3; s++) {
+           integ.integrate(&d1, &one, 0.001f);
+           integ.integrate(&d2, &many, 0.001f);
+         }
+         ParticleDataManager::copyToHost(h1, d1);
+         ParticleDataManager::copyToHost(h2, d2);
+         double worst_a = 0, worst_x = 0;
+         for (size_t i = 0; i < n; i++) {
+           const double ax = h1.acc_x[i], ay = h1.acc_y[i], az = h1.acc_z[i];
+           const double dx = h2.acc_x[i] - ax, dy = h2.acc_y[i] - ay, dz = h2.acc_z[i] - az;
+           worst_a = std::fmax(worst_a, std::sqrt(dx * dx + dy * dy + dz * dz) / std::sqrt(ax * ax + ay * ay + az * az));
+           worst_x = std::fmax(worst_x, std::fabs((double)h2.pos_x[i] - h1.pos_x[i]) + std::fabs((double)h2.vel_y[i] - h1.vel_y[i]));
+         }
+         std::printf("  sharded vs single: max rel acc diff %.3e, max |dx|+|dvy| %.3e\n", worst_a, worst_x);
+         CHECK(worst_a < 1e-5); CHECK(worst_x < 1e-5);
+         // the setters are plain stores read at the next call
+         many.setSofteningParameter(0.2f);
+         one.setSofteningParameter(0.2f);
+         one.computeForces(&d1); many.computeForces(&d2);
+         ParticleDataManager::copyToHost(h1, d1); ParticleDataManager::copyToHost(h2, d2);
+         CHECK_NEAR(h1.acc_x[17], h2.acc_x[17], 1e-5 * std::fabs(h1.acc_x[17]) + 1e-9);
+         ParticleDataManager::freeDevice(d1); ParticleDataManager::freeDevice(d2);
+         ParticleDataManager::freeHost(h1); ParticleDataManager::freeHost(h2);
+       }},
   };
   for (auto& c : cases) {
     const int before = g_fail;

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "nbody_hip.h")).read()
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include")))
+                  if h.endswith(".h"))   # nbody_hip.h and nbody_hip_comm.h
     return sorted(set(re.findall(r"NBODY_HIP_API\s+[\w\s\*]+?\b(nbody_hip_\w+)\s*\(", src)))
 
 

@@ -1,0 +1,171 @@
+"""The multi-GPU layer behind the C ABI (include/nbody_hip_comm.h, csrc/sharded.hip) on the test box's ONE GPU:
+  * transport P2P with 1-8 VIRTUAL ranks on device 0 -- the whole orchestration of BASELINE config 3's step
+    (index-range shards, all-gather by peer copies || own x own, every shard pair once, point-to-point
+    reaction exchange, fixed-order sum + kick, events between the ranks' streams) against the single-GPU
+    engine and the oracle;
+  * transport RCCL with the one rank a box has (ncclCommInitRank / ncclCommInitAll, in-place all-gather,
+    grouped send / recv code path with an empty schedule);
+  * the plugin form (whole-system ParticleData in, accelerations out) through Integrator.integrate.
+RCCL refuses two ranks on one device, so the W > 1 RCCL exchange is first run by the driver's multi-GPU bench."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import acc_of, packed, rel_err, to_device
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _single_gpu(nb, ic, G, eps, dt, steps):
+    d, _ = to_device(nb, ic)
+    fc = nb.DirectForceCalculator()
+    fc.setGravitationalConstant(G)
+    fc.setSofteningParameter(eps)
+    fc.computeForces(d)
+    a0 = acc_of(d)
+    integ = nb.Integrator()
+    for _ in range(steps):
+        integ.integrate(d, fc, dt)
+    state = {k: getattr(d, k).cpu().numpy() for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z",
+                                                       "acc_x", "acc_y", "acc_z")}
+    return a0, state, (integ.computeKineticEnergyF64(d) if hasattr(integ, "computeKineticEnergyF64") else None)
+
+
+@pytest.mark.parametrize("W,n,masses", [(1, 20000, "equal"), (2, 30001, "equal"), (3, 30000, "random"), (4, 50003, "equal"),
+                                        (8, 140000, "equal"), (8, 40000, "random"), (5, 9, "equal")])
+def test_virtual_ranks_step_equals_single_gpu_and_oracle(nb, oracle, ctx, W, n, masses):
+    from nbody_amd.sharded import TRANSPORT_P2P, Comm, ShardedDirect
+    G, eps, dt, steps = 1.3, 0.01, 1e-3, 3
+    ic = nb.ic.plummer(n, seed=100 + W)
+    if masses == "random":
+        ic["mass"] = (ic["mass"] * np.random.default_rng(W).uniform(0.5, 2.0, n)).astype(np.float32)
+    comm = Comm.init_all(W, [0] * W, TRANSPORT_P2P)
+    assert comm.info() == {"world": W, "nlocal": W, "transport": TRANSPORT_P2P, "local_ranks": list(range(W))}
+    sysm = ShardedDirect(comm, n, G, eps)
+    sysm.set_state(ic)
+    sysm.forces()
+    a_sh = np.stack([sysm.get_state()[k] for k in ("acc_x", "acc_y", "acc_z")], 1)
+    a0, ref_state, _ = _single_gpu(nb, ic, G, eps, dt, steps)
+    assert rel_err(a_sh, a0).max() < TOL
+    eps2 = float(np.float32(eps) * np.float32(eps))
+    idx = np.unique(np.concatenate([np.random.default_rng(1).choice(n, min(n, 512), replace=False), [0, n - 1]]))
+    orc = np.stack(oracle.direct_forces_indexed(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], idx, G, eps2, 1), 1)
+    assert rel_err(a_sh[idx], orc).max() < TOL
+    ke0, pe0 = sysm.energies()
+    sysm.step(dt, steps)
+    st = sysm.get_state()
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert np.allclose(st[k], ref_state[k], rtol=1e-5, atol=1e-6), k
+    a_ref = np.stack([ref_state[k] for k in ("acc_x", "acc_y", "acc_z")], 1)
+    assert rel_err(np.stack([st[k] for k in ("acc_x", "acc_y", "acc_z")], 1), a_ref).max() < 2e-5
+    # energies: the shards' sums equal the oracle's fp64 reductions of the same state
+    s0 = {k: np.ascontiguousarray(ic[k], np.float32) for k in ic}
+    assert abs(ke0 - oracle.kinetic_energy(s0, 256, 2)) <= 1e-6 * abs(ke0) + 1e-12
+    assert abs(pe0 - oracle.potential_energy(s0, G, eps, 256, 2)) <= 1e-5 * abs(pe0)
+    ke1, pe1 = sysm.energies()
+    assert abs((ke1 + pe1) - (ke0 + pe0)) < 1e-4 * abs(pe0)
+    # bitwise reproducible run after run (deterministic two-set kernel + fixed-order sum of the received blocks)
+    again = ShardedDirect(comm, n, G, eps)
+    again.set_state(ic)
+    again.forces()
+    again.step(dt, steps)
+    st2 = again.get_state()
+    for k in st:
+        assert np.array_equal(st[k], st2[k]), k
+    again.close()
+    sysm.close()
+    comm.close()
+
+
+def test_virtual_ranks_tiny_softening_takes_the_one_sided_path(nb, oracle, ctx):
+    from nbody_amd.sharded import Comm, ShardedDirect
+    n, W = 6001, 3
+    ic = nb.ic.plummer(n, seed=5)
+    comm = Comm.init_all(W, [0] * W)
+    sysm = ShardedDirect(comm, n, 1.0, 0.0)      # eps = 0: no pair kernel, rank r sums the gathered shards one-sided
+    sysm.set_state(ic)
+    sysm.forces()
+    st = sysm.get_state()
+    a = np.stack([st[k] for k in ("acc_x", "acc_y", "acc_z")], 1)
+    ref = np.stack(oracle.direct_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0, 0.0, 1), 1)
+    assert rel_err(a, ref).max() < TOL
+    sysm.step(1e-4, 2)
+    assert np.all(np.isfinite(sysm.get_state()["pos_x"]))
+
+
+@pytest.mark.parametrize("how", ["init_rank", "init_all"])
+def test_one_rccl_rank(nb, ctx, how):
+    """ncclCommInitRank / ncclCommInitAll with the box's one GPU: librccl.so.1 is opened at run time, the step's
+    RCCL calls (in-place all-gather; the grouped exchange is empty at W = 1) run, results equal the P2P transport."""
+    from nbody_amd.sharded import TRANSPORT_RCCL, Comm, ShardedDirect
+    n = 20000
+    ic = nb.ic.plummer(n, seed=3)
+    if how == "init_rank":
+        uid = Comm.unique_id()
+        assert len(uid) == 128 and any(uid)
+        comm = Comm.init_rank(0, 0, 1, uid)
+    else:
+        comm = Comm.init_all(1, [0], TRANSPORT_RCCL)
+    assert comm.info()["transport"] == TRANSPORT_RCCL and comm.info()["world"] == 1
+    a = ShardedDirect(comm, n, 1.0, 0.02)
+    a.set_state(ic)
+    a.forces()
+    a.step(1e-3, 2)
+    ms = a.time_steps(1e-3, 1, 3)
+    assert 0 < ms < 1000
+    st = a.get_state()
+    ke, pe = a.energies()
+    p2p = Comm.init_all(1, [0])
+    b = ShardedDirect(p2p, n, 1.0, 0.02)
+    b.set_state(ic)
+    b.forces()
+    b.step(1e-3, 6)
+    st_b = b.get_state()
+    for k in st:
+        assert np.array_equal(st[k], st_b[k]), k
+    assert (ke, pe) == b.energies()
+    with pytest.raises(nb.ValidationException):
+        Comm.init_all(2, [0, 0], TRANSPORT_RCCL)       # RCCL needs distinct devices
+    a.close(); b.close(); comm.close(); p2p.close()
+
+
+# The plugin form: a multi-rank ForceCalculator behind the reference's interface -- computeForces(ParticleData*)
+# on a whole-system ParticleData -- driven by the unchanged Integrator (its generic path: a subclass goes through
+# the virtual computeForces, force_calculator.hpp:36-58)
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_plugin_form_through_integrator(nb, ctx, W):
+    from nbody_amd.sharded import Comm, ShardedDirect
+    n, G, eps, dt = 60000, 1.0, 0.05, 1e-3
+    ic = nb.ic.plummer(n, seed=W)
+
+    class ShardedCalculator(nb.ForceCalculator):
+        def __init__(self):
+            super().__init__()
+            self.comm = Comm.init_all(W, [0] * W)
+            self.sys = ShardedDirect(self.comm, n, G, eps)
+
+        def computeForces(self, d):
+            self.sys.compute_forces(d)
+
+        def getMethod(self):
+            return nb.ForceMethod.DIRECT_N2
+    d1, _ = to_device(nb, ic)
+    d2, _ = to_device(nb, ic)
+    one = nb.DirectForceCalculator()
+    one.setGravitationalConstant(G)
+    one.setSofteningParameter(eps)
+    many = ShardedCalculator()
+    one.computeForces(d1)
+    many.computeForces(d2)
+    assert rel_err(acc_of(d2), acc_of(d1)).max() < TOL
+    integ = nb.Integrator()
+    for _ in range(3):
+        integ.integrate(d1, one, dt)
+        integ.integrate(d2, many, dt)
+    torch.cuda.synchronize()
+    for k in ("pos_x", "vel_y", "acc_z"):
+        assert np.allclose(getattr(d2, k).cpu().numpy(), getattr(d1, k).cpu().numpy(), rtol=2e-5, atol=1e-6), k
+    with pytest.raises(nb.ValidationException):
+        small, _ = to_device(nb, nb.ic.plummer(100, seed=1))
+        many.sys.compute_forces(small)
