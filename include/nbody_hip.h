@@ -327,6 +327,11 @@ NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int 
  * (even siblings) + (odd siblings)), its waves scheduled longest-first from the node visits the previous walk
  * recorded; 3 = pair walk in plain order; 0 = automatic (2).  Results do not depend on the schedule. */
 NBODY_HIP_API int nbody_hip_tree_walk_form(nbody_hip_tree* tree, int form);
+/* Test / stress hook: cap the node arrays at `max_nodes` (0 = the bound on the node count; the arrays also stop
+ * at 2^28 - 1 nodes, the width of a child link).  A tree that would need more nodes is cut where the numbering
+ * passes the capacity: the nodes beyond do not exist and their parents are leaves of several bodies, which interact
+ * body by body -- forces stay correct (closer to the direct sum than the full tree's), the walk gets slower. */
+NBODY_HIP_API int nbody_hip_tree_limit_nodes(nbody_hip_tree* tree, int max_nodes);
 /* Node-visit counting for nbody_hip_tree_stats (off by default: it costs a memset launch and an
  * atomic per wave in every walk). */
 NBODY_HIP_API int nbody_hip_tree_count_visits(nbody_hip_tree* tree, int enable);

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "nbody_hip_tree_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nbody_hip_tree_destroy": (C.c_int, [_P]),
     "nbody_hip_tree_set_params": (C.c_int, [_P, C.c_int, C.c_int]),
+    "nbody_hip_tree_limit_nodes": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_tree_walk_form": (C.c_int, [_P, C.c_int]),
     "nbody_hip_tree_visit_histogram": (C.c_int, [_P, C.POINTER(C.c_ulonglong * 130)]),

@@ -655,6 +655,10 @@ class BarnesHutTree:
     def tuning(self, replicas: int = 0, split_level: int = 0):
         check(self.ctx._lib.nbody_hip_tree_tuning(self._h, replicas, split_level))
 
+    def limitNodes(self, max_nodes: int = 0):
+        """cap the node arrays (nbody_hip_tree_limit_nodes): a tree that needs more is cut, forces stay correct"""
+        check(self.ctx._lib.nbody_hip_tree_limit_nodes(self._h, max_nodes))
+
     def walkForm(self, form: int = 0):
         """walk without replicas: 0 automatic, 1 plain, 2 pair walk (cost-ordered), 3 pair walk in plain order"""
         check(self.ctx._lib.nbody_hip_tree_walk_form(self._h, form))
@@ -688,6 +692,12 @@ class BarnesHutTree:
 
     def getNodeCount(self) -> int:
         return self.stats()["node_count"]
+
+    def getMaxDepth(self) -> int:
+        """deepest level that holds nodes (ref: BarnesHutTree::getMaxDepth, barnes_hut_tree.hpp:43: the depth the
+        insertion reached)"""
+        lb = self.stats()["level_base"]
+        return max([l - 1 for l in range(1, len(lb)) if lb[l] > lb[l - 1]] + [0])
 
     def copyNodesToHost(self):
         n = self.getNodeCount()

@@ -34,9 +34,6 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -193,7 +190,8 @@ struct TreeArrays {
   //          several bodies; one-body leaf: 0; leaf of several bodies: kManyLeaf
   unsigned int* pb;
   // leaves of several bodies only exist where a node may not be split: below level scan_from (the depth limit,
-  // or everywhere with leaf_max > 1) or when the node arrays overflowed (*node_total > capacity)
+  // or everywhere with leaf_max > 1) or when the node arrays overflowed (*node_total > capacity; node_total is
+  // the UNCLAMPED count the numbering arrived at, level_base[kMaxDepth + 2])
   int scan_from, capacity;
   const int* node_total;
 };
@@ -218,6 +216,19 @@ __device__ __forceinline__ void store_node(const TreeArrays& t, int nid, int lev
   q[10] = link;
 }
 
+// the same for a caller that already knows whether a child is a leaf of several bodies (fused fill pass)
+__device__ __forceinline__ void store_node_fused(const TreeArrays& t, int nid, const NodeRec& r, bool many) {
+  t.rec[nid] = r;
+  const bool leaf = r.child == 0u;
+  unsigned int link = leaf ? (r.count == 1 ? 0u : kManyLeaf) : ((r.child & 0x0fffffffu) | (((r.child >> 28) - 1u) << 28));
+  if (!leaf && many) link |= kManyBit;
+  unsigned int* q = t.pb + (size_t)(nid >> 1) * kPairWords + (nid & 1);
+  q[0] = __float_as_uint(r.cx); q[2] = __float_as_uint(r.cy); q[4] = __float_as_uint(r.cz);
+  q[6] = __float_as_uint((leaf && r.count != 1) ? 0.f : r.mass);
+  q[8] = __float_as_uint(leaf ? -1.0f : r.size2);
+  q[10] = link;
+}
+
 // ---------------------------------------------------------------------------------------
 // Topology from the sorted keys alone, all levels at once.
 //
@@ -225,9 +236,9 @@ __device__ __forceinline__ void store_node(const TreeArrays& t, int nid, int lev
 // holds more than leaf_max bodies (force_barnes_hut.cu:197-209: a node is split while it holds
 // more than one body; counts shrink monotonically down a branch, so the parent test implies
 // every ancestor's).  Both facts are local in the sorted key list, so one kernel flags the first
-// body of every node of every level (flag[L * n + i]), ONE inclusive scan over the level-major
-// flag array numbers the nodes (ids ascend by level, then by key = octant order; the children of
-// a node are consecutive), and one kernel fills the ranges and child links from that scan.
+// body of every node of every level, the flags are ranked per level (LevelRanks below: ids ascend
+// by level, then by key = octant order; the children of a node are consecutive), and one kernel
+// fills the ranges and child links from the ranks.
 // ---------------------------------------------------------------------------------------
 
 // how many of the `cap` bodies on one side of body i (dir = -1 / +1) share its prefix (key >> sp)
@@ -241,78 +252,151 @@ __device__ __forceinline__ int side_extent(const K* __restrict__ keys, int i, in
   return lo;
 }
 
+// Node numbering without a scan over the (levels x n) flag array (round 2: one rocPRIM inclusive scan through a
+// transform iterator, 84 us and an 88 MB output at N = 2^20, 21 levels).  The flags of level L are kept as BIT PLANES:
+// plane[L][g] = ballot of the level-L flag over the 64 bodies of group g (= one wave of tree_flags_kernel), and
+// off[L][g] = number of level-L flags before group g (one small workgroup per level scans the popcounts).  The
+// inclusive rank of body j at level L -- how many level-L nodes start at or before j -- is then two loads and a
+// popcount, wherever j lies; node id = (nodes of the levels above) + rank - 1.  4.3 MB of tables at N = 2^20.
+struct LevelRanks {
+  const unsigned long long* plane;  // [levels][G]
+  const int* off;                   // [levels][G]: exclusive prefix of the popcounts of a level
+  int G;
+  __device__ __forceinline__ int rank(int L, int j) const {  // inclusive
+    const size_t w = (size_t)L * G + (size_t)(j >> 6);
+    return off[w] + __popcll(plane[w] & (~0ull >> (63 - (j & 63))));
+  }
+  // position of the r-th (1-based) flag of level L; r must be <= the level's total
+  __device__ __forceinline__ int select(int L, int r) const {
+    const int* o = off + (size_t)L * G;
+    int lo = 0, hi = G - 1;  // largest g with off[g] < r
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (o[mid] < r) lo = mid; else hi = mid - 1;
+    }
+    unsigned long long w = plane[(size_t)L * G + lo];
+    for (int k = r - o[lo]; k > 1; k--) w &= w - 1;  // drop the lowest k - 1 set bits
+    return (lo << 6) + __ffsll((long long)w) - 1;
+  }
+};
+
 template <class K>
 __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict__ keys,
                                                             int n, int max_depth, int leaf_max,
                                                             unsigned int* __restrict__ lvlmask,
                                                             const float4* __restrict__ posm,
                                                             const int* __restrict__ sorted_idx,
-                                                            float4* __restrict__ sorted) {
+                                                            float4* __restrict__ sorted,
+                                                            unsigned long long* __restrict__ plane,
+                                                            int* __restrict__ cnt, int G) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  sorted[i] = posm[sorted_idx[i]];  // the bodies in Morton order (the gather rides along: one launch less)
-  const K k = keys[i];
-  // first body of its group at level L  <=>  (d >> (top - 3L)) != 0; body 0 heads every level
-  const K d = i == 0 ? ~(K)0 : (k ^ keys[i - 1]);
-  bool open = true;  // the parent group is an internal node (level 0 has no parent)
   unsigned int mask = 0;
-  for (int L = 0; L <= max_depth; L++) {
-    const int shift = KeyTraits<K>::kTop - 3 * L;
-    if (L > 0 && open) {
-      const int sp = shift + 3;
-      const K prefix = k >> sp;
-      const int a = side_extent(keys, i, -1, min(i, leaf_max), prefix, sp);
-      int b = 0;
-      if (a < leaf_max) b = side_extent(keys, i, +1, min(n - 1 - i, leaf_max - a), prefix, sp);
-      open = a + b >= leaf_max;  // parent holds at least a + b + 1 > leaf_max bodies
+  if (i < n) {
+    sorted[i] = posm[sorted_idx[i]];  // the bodies in Morton order (the gather rides along: one launch less)
+    const K k = keys[i];
+    // first body of its group at level L  <=>  (d >> (top - 3L)) != 0; body 0 heads every level
+    const K d = i == 0 ? ~(K)0 : (k ^ keys[i - 1]);
+    bool open = true;  // the parent group is an internal node (level 0 has no parent)
+    for (int L = 0; L <= max_depth; L++) {
+      const int shift = KeyTraits<K>::kTop - 3 * L;
+      if (L > 0 && open) {
+        const int sp = shift + 3;
+        const K prefix = k >> sp;
+        const int a = side_extent(keys, i, -1, min(i, leaf_max), prefix, sp);
+        int b = 0;
+        if (a < leaf_max) b = side_extent(keys, i, +1, min(n - 1 - i, leaf_max - a), prefix, sp);
+        open = a + b >= leaf_max;  // parent holds at least a + b + 1 > leaf_max bodies
+      }
+      const bool node = open && (d >> shift) != 0;
+      if (node) mask |= 1u << L;
     }
-    const bool node = open && (d >> shift) != 0;
-    if (node) mask |= 1u << L;
+    // levels at which body i heads a node (the fill pass walks the set bits)
+    lvlmask[i] = mask;
   }
-  // levels at which body i heads a node: bit L = the flag of entry (L, i) of the level-major flag array.  The array
-  // itself is never written: the scan reads it through LevelFlag, the fill pass walks the set bits only.
-  lvlmask[i] = mask;
+  // the wave's ballot of every level -> lane L keeps level L's and writes it with its popcount
+  const int lane = threadIdx.x & 63, g = i >> 6;
+  unsigned long long mine = 0;
+  for (int L = 0; L <= max_depth; L++) {
+    const unsigned long long b = __ballot((mask >> L) & 1u);
+    if (lane == L) mine = b;
+  }
+  if (lane <= max_depth && g < G) {
+    plane[(size_t)lane * G + g] = mine;
+    cnt[(size_t)lane * G + g] = __popcll(mine);
+  }
 }
 
-// entry e = L * n + i of the level-major flag array, read from the per-body level masks (the scan's input)
-struct LevelFlag {
-  const unsigned int* lvlmask;
-  unsigned int n;
-  __host__ __device__ int operator()(unsigned int e) const {
-    const unsigned int L = e / n, i = e - L * n;
-    return (int)((lvlmask[i] >> L) & 1u);
+// one workgroup per level: off[L][g] <- number of level-L flags before group g (in place over the popcounts),
+// totals[L] <- nodes of the level
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void level_scan_kernel(int* __restrict__ off, int G, int* __restrict__ totals) {
+  __shared__ int part[kScanBlock];
+  const int L = blockIdx.x, tid = threadIdx.x;
+  int* o = off + (size_t)L * G;
+  const int per = (G + kScanBlock - 1) / kScanBlock;
+  const int g0 = min(G, tid * per), g1 = min(G, g0 + per);
+  int sum = 0;
+  for (int g = g0; g < g1; g++) sum += o[g];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < kScanBlock; d <<= 1) {  // inclusive scan of the chunk sums
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
   }
-};
-__host__ __device__ inline auto level_flags(const unsigned int* lvlmask, unsigned int n) {
-  return rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u), LevelFlag{lvlmask, n});
+  int run = part[tid] - sum;
+  for (int g = g0; g < g1; g++) {
+    const int c = o[g];
+    o[g] = run;
+    run += c;
+  }
+  if (tid == kScanBlock - 1) totals[L] = part[tid];
 }
 
 // One thread per BODY: it fills the nodes this body heads (the set bits of its level mask; 1.3 nodes per
 // body on average), instead of one thread per (level, body) entry of the flag array, 21 of 22 of which
 // would only find a zero flag (145 -> 60 us at N = 2^20, 21 levels).
-template <class K>
+// FUSED (trees of <= kPrefixMax bodies): the node's monopole comes from the double-double prefix sums over the sorted
+// bodies right here -- no second pass over the nodes (prefix_monopole_kernel of round 2: 49 us and a re-read of the
+// four range / link arrays).
+struct dd4;
+struct PrefixSums {
+  const dd4* P;     // entry k = sums over the workgroup's bodies before k
+  const dd4* boff;  // workgroup offsets
+};
+__device__ __forceinline__ double4 prefix_monopole(const PrefixSums& ps, const float4* __restrict__ sorted, int first, int last);
+__device__ __forceinline__ void store_node_fused(const TreeArrays& t, int nid, const NodeRec& r, bool many);
+
+template <class K, bool FUSED>
 __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__ keys,
                                                            int n, int max_depth, int leaf_max,
                                                            const unsigned int* __restrict__ lvlmask,
-                                                           const int* __restrict__ incl,
+                                                           LevelRanks lr, const int* __restrict__ totals,
                                                            TreeArrays t, int capacity,
-                                                           int* __restrict__ level_base) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i <= max_depth) {  // thread L of the first block (256 > levels): ids of level L start where the scan of
-    const int L = i;     // the levels above ended
-    const size_t total = (size_t)(max_depth + 1) * n;
-    level_base[L] = L == 0 ? 0 : min(incl[(size_t)L * n - 1], capacity);
-    if (L == max_depth) level_base[L + 1] = min(incl[total - 1], capacity);
+                                                           int* __restrict__ level_base,
+                                                           const float4* __restrict__ sorted, PrefixSums ps,
+                                                           const TreeRoot* __restrict__ root) {
+  // ids of level L start where the levels above end: ubase (unclamped; an id >= capacity does not exist)
+  __shared__ int ubase[kMaxDepth + 3];
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int L = 0; L <= max_depth; L++) { ubase[L] = run; run += totals[L]; }
+    ubase[max_depth + 1] = run;
   }
+  __syncthreads();
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i <= max_depth + 1) level_base[i] = min(ubase[i], capacity);  // thread L of the first block (256 > levels)
+  if (i == 0) level_base[kMaxDepth + 2] = ubase[max_depth + 1];     // the UNCLAMPED node total (TreeArrays::node_total)
   if (i >= n) return;
+  const bool overflow = ubase[max_depth + 1] > capacity;
   unsigned int m = lvlmask[i];
   const K key = keys[i];
   while (m) {
     const int L = __ffs(m) - 1;
     m &= m - 1;
-    const size_t e = (size_t)L * n + i;
-    const int nid = incl[e] - 1;
-    if (nid >= capacity) continue;  // cannot happen with the capacity bound; never write past it
+    const int nid = ubase[L] + lr.rank(L, i) - 1;
+    if (nid >= capacity) continue;  // beyond the node arrays: this node does not exist (its parent is a leaf)
     const int shift = KeyTraits<K>::kTop - 3 * L;
     // one past the last body of the group: first j > i with another prefix
     int last = n;
@@ -334,13 +418,45 @@ __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__
     int c0 = -1, c1 = -1;
     if (L < max_depth && last - i > leaf_max) {
       // children: the flagged bodies of level L + 1 inside [i, last); body i is always one of them
-      const size_t ce = (size_t)(L + 1) * n;
-      c0 = incl[ce + i] - 1;
-      c1 = incl[ce + last - 1] - 1;
+      c0 = ubase[L + 1] + lr.rank(L + 1, i) - 1;
+      c1 = ubase[L + 1] + lr.rank(L + 1, last - 1) - 1;
       if (c1 >= capacity) { c0 = -1; c1 = -1; }
     }
     t.child0[nid] = c0;
     t.child_last[nid] = c1;
+    if constexpr (FUSED) {
+      const int cnt = last - i;
+      const double4 mono = prefix_monopole(ps, sorted, i, last);
+      const float h = ldexpf(root->half, -L);
+      const float size = 2.0f * h;  // :168
+      NodeRec r;
+      r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
+      r.size2 = size * size;
+      r.first = i; r.count = cnt;
+      r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(c1 - c0 + 1) << 28));
+      // is one of the children a leaf of several bodies?  Only where a node may not be split: at the depth limit,
+      // with leaf_max > 1, or when the node arrays overflowed.  Asked of the bit planes (the children's own records
+      // are being written by other threads of this very launch).
+      bool many = false;
+      if (c0 >= 0 && (L + 1 >= t.scan_from || overflow)) {
+        const int nchild = c1 - c0 + 1;
+        if (L + 1 == max_depth) {
+          many = cnt > nchild;  // every child is a leaf: some child holds two or more bodies
+        } else {
+          const int r0 = lr.rank(L + 1, i);
+          int h0 = i;
+          for (int k = 0; k < nchild && !many; k++) {
+            const int h1 = k + 1 < nchild ? lr.select(L + 1, r0 + k + 1) : last;
+            const int cc = h1 - h0;
+            bool leaf = cc <= leaf_max;
+            if (!leaf) leaf = ubase[L + 2] + lr.rank(L + 2, h1 - 1) - 1 >= capacity;  // its children do not exist
+            many = leaf && cc != 1;
+            h0 = h1;
+          }
+        }
+      }
+      store_node_fused(t, nid, r, many);
+    }
   }
 }
 
@@ -542,44 +658,24 @@ __global__ __launch_bounds__(kPrefixBlock) void prefix_blocks_kernel(int nblocks
   }
 }
 
-__global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __restrict__ level_base, int max_depth,
-                                                                 const float4* __restrict__ sorted,
-                                                                 const dd4* __restrict__ P,
-                                                                 const dd4* __restrict__ boff,
-                                                                 const TreeRoot* __restrict__ root, TreeArrays t) {
-  const int nid = blockIdx.x * kBlock + threadIdx.x;
-  if (nid >= level_base[max_depth + 1]) return;
-  int level = 0;
-  while (level < max_depth && nid >= level_base[level + 1]) level++;
-  const int first = t.first[nid], last = t.last[nid], cnt = last - first;
-  const int c0 = t.child0[nid];
-  double4 mono;
-  if (cnt == 1) {
+// monopole {com, mass} of the sorted bodies [first, last) from the prefix sums (a one-body node is its body)
+__device__ __forceinline__ double4 prefix_monopole(const PrefixSums& ps, const float4* __restrict__ sorted, int first, int last) {
+  if (last - first == 1) {
     const float4 p = sorted[first];
-    mono = make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
-  } else {
-    // (P[last] + boff[its workgroup]) - (P[first] + boff[its workgroup]) in double-double
-    dd4 hi = P[last], lo = P[first];
-    const dd4 oh = boff[last / kPrefixBlock], ol = boff[first / kPrefixBlock];
-    double s[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      dd_add(hi.hi[c], hi.lo[c], oh.hi[c], oh.lo[c]);
-      dd_add(lo.hi[c], lo.lo[c], ol.hi[c], ol.lo[c]);
-      dd_add(hi.hi[c], hi.lo[c], -lo.hi[c], -lo.lo[c]);
-      s[c] = hi.hi[c] + hi.lo[c];
-    }
-    mono = s[3] > 0.0 ? make_double4(s[0] / s[3], s[1] / s[3], s[2] / s[3], s[3])
-                      : make_double4(0.0, 0.0, 0.0, 0.0);
+    return make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
   }
-  const float h = ldexpf(root->half, -level);
-  const float size = 2.0f * h;  // :168
-  NodeRec r;
-  r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
-  r.size2 = size * size;
-  r.first = first; r.count = cnt;
-  r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
-  store_node(t, nid, level, r);
+  // (P[last] + boff[its workgroup]) - (P[first] + boff[its workgroup]) in double-double
+  dd4 hi = ps.P[last], lo = ps.P[first];
+  const dd4 oh = ps.boff[last / kPrefixBlock], ol = ps.boff[first / kPrefixBlock];
+  double s[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    dd_add(hi.hi[c], hi.lo[c], oh.hi[c], oh.lo[c]);
+    dd_add(lo.hi[c], lo.lo[c], ol.hi[c], ol.lo[c]);
+    dd_add(hi.hi[c], hi.lo[c], -lo.hi[c], -lo.lo[c]);
+    s[c] = hi.hi[c] + hi.lo[c];
+  }
+  return s[3] > 0.0 ? make_double4(s[0] / s[3], s[1] / s[3], s[2] / s[3], s[3]) : make_double4(0.0, 0.0, 0.0, 0.0);
 }
 
 constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; [66..130] by lanes accepting
@@ -1088,7 +1184,12 @@ struct nbody_hip_tree {
   bool wide() const { return max_depth > kDepth32; }
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
-  int* d_incl = nullptr;  // (max_depth + 1) * max_particles, level-major: inclusive scan of the node flags
+  // node numbering (LevelRanks): bit planes and per-group offsets of every level, the level totals
+  unsigned long long* d_plane = nullptr;  // (max_depth + 1) * rank_G
+  int* d_rank_off = nullptr;              // (max_depth + 1) * rank_G
+  int* d_totals = nullptr;                // kMaxDepth + 3
+  int rank_G = 0;                         // groups of 64 bodies at max_particles
+  int node_limit = 0;                     // nbody_hip_tree_limit_nodes: 0 = the bound on the node count
   TreeArrays t{};
   void* d_tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -1111,7 +1212,7 @@ struct nbody_hip_tree {
 static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
-                  g->d_idx_b, g->d_sorted, g->d_incl,
+                  g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, g->d_totals,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
   for (void* p : ptrs) (void)hipFree(p);
@@ -1127,24 +1228,31 @@ static hipError_t dmalloc(T** p, size_t count) {
 // arrays, the sort / scan scratch and the node arrays
 static int tree_alloc_nodes(nbody_hip_tree* g) {
   void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
-                  g->d_keys_a, g->d_keys_b, g->d_incl, g->d_tmp};
+                  g->d_keys_a, g->d_keys_b, g->d_plane, g->d_rank_off, g->d_tmp};
   for (void* p : ptrs) (void)hipFree(p);
   g->t = TreeArrays{};
   g->d_keys_a = g->d_keys_b = nullptr;
-  g->d_incl = nullptr;
+  g->d_plane = nullptr;
+  g->d_rank_off = nullptr;
   g->d_tmp = nullptr;
   const size_t n = g->max_particles;
   // leaves <= n; internal nodes per level <= n / (leaf_max + 1)
   size_t cap = n + (size_t)(g->max_depth + 1) * (n / (size_t)(g->leaf_max + 1) + 1) + 16;
-  if (cap > 0x0fffffffu) cap = 0x0fffffffu;  // 28-bit child ids
+  // 28-bit child ids.  A tree that would need more nodes than the arrays hold is cut where the numbering passes the
+  // capacity: the nodes beyond do not exist, their parents become leaves of several bodies (exact body-by-body
+  // interactions; tree_fill_kernel / store_node flag them from the UNCLAMPED node total) -- slower, never wrong.
+  if (cap > 0x0fffffffu) cap = 0x0fffffffu;
+  if (g->node_limit > 0 && (size_t)g->node_limit < cap) cap = (size_t)g->node_limit;
   g->capacity = (int)cap;
   const size_t kbytes = n * (g->wide() ? sizeof(unsigned long long) : sizeof(unsigned int));
-  const size_t nflag = (size_t)(g->max_depth + 1) * n;
+  g->rank_G = (int)((n + 63) / 64);
+  const size_t nrank = (size_t)(g->max_depth + 1) * (size_t)g->rank_G;
   hipError_t e = hipMalloc(&g->d_keys_a, kbytes);
   if (e == hipSuccess) e = hipMalloc(&g->d_keys_b, kbytes);
-  if (e == hipSuccess) e = dmalloc(&g->d_incl, nflag);
+  if (e == hipSuccess) e = dmalloc(&g->d_plane, nrank);
+  if (e == hipSuccess) e = dmalloc(&g->d_rank_off, nrank);
   if (e == hipSuccess) {
-    size_t t1 = 0, t2 = 0;
+    size_t t1 = 0;
     if (g->wide())
       e = rocprim::radix_sort_pairs<SortConfig64>(nullptr, t1, static_cast<unsigned long long*>(g->d_keys_a),
                                                 static_cast<unsigned long long*>(g->d_keys_b), g->d_idx_a, g->d_idx_b,
@@ -1153,10 +1261,7 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
       e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, static_cast<unsigned int*>(g->d_keys_a),
                                                 static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
                                                 30, g->ctx->stream);
-    if (e == hipSuccess)
-      e = rocprim::inclusive_scan(nullptr, t2, level_flags(nullptr, (unsigned int)n), g->d_incl, nflag,
-                                  rocprim::plus<int>(), g->ctx->stream);
-    g->tmp_bytes = t1 > t2 ? t1 : t2;
+    g->tmp_bytes = t1;
     if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
   }
   if (e == hipSuccess) e = dmalloc(&g->t.first, cap);
@@ -1174,7 +1279,7 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
                     hipGetErrorString(e));
   g->t.scan_from = g->leaf_max > 1 ? 0 : g->max_depth;
   g->t.capacity = g->capacity;
-  g->t.node_total = g->d_level_base + g->max_depth + 1;
+  g->t.node_total = g->d_level_base + kMaxDepth + 2;  // the unclamped total (tree_fill_kernel)
   return NBODY_HIP_OK;
 }
 
@@ -1191,6 +1296,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   hipError_t e = dmalloc(&g->d_enc, 16);
   if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
+  if (e == hipSuccess) e = dmalloc(&g->d_totals, kMaxDepth + 3);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_a, n);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_b, n);
   if (e == hipSuccess) e = dmalloc(&g->d_sorted, n);
@@ -1246,6 +1352,19 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
   return tree_alloc_nodes(g);
 }
 
+// test / stress hook: cap the node arrays below the bound on the node count (0 = the bound).  A tree that needs more
+// nodes is cut at the capacity (see tree_alloc_nodes): forces stay exact-or-better, only slower.
+extern "C" int nbody_hip_tree_limit_nodes(nbody_hip_tree* g, int max_nodes) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
+  if (max_nodes < 0 || (max_nodes > 0 && max_nodes < 16)) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_nodes must be 0 or >= 16");
+  NBH_HIP(hipSetDevice(g->ctx->device));
+  NBH_HIP(hipStreamSynchronize(g->ctx->stream));
+  g->node_limit = max_nodes;
+  g->built_count = 0;
+  g->ctx->alloc_generation++;
+  return tree_alloc_nodes(g);
+}
+
 // the build proper, from packed bodies
 // soa != nullptr: posm is a scratch array to be filled from the SoA bodies (fused with the bounding box)
 // drift_dt: soa is a step's state BEFORE its drift; the drift rides on the packing pass (nbody_hip_tree_drift_build)
@@ -1273,7 +1392,7 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   }
   // topology of every level: keys, sort, flags, one scan, fill (see tree_flags_kernel)
   const int levels = g->max_depth + 1;
-  const size_t total = (size_t)levels * n;
+  const bool fused = ni <= kPrefixMax;
   auto topology = [&](auto* ka, auto* kb, int first_bit, int key_bits) -> int {
     using K = std::remove_pointer_t<decltype(ka)>;
     hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, enc, enc_next, g->d_root,
@@ -1285,15 +1404,29 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
     NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
     unsigned int* lvlmask = reinterpret_cast<unsigned int*>(g->d_idx_a);  // idx_a is free after the sort
+    // the ranks are laid out for THIS build's body count: G groups of 64 (<= rank_G, the allocation)
+    const int G = (ni + 63) / 64;
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       lvlmask, posm, g->d_idx_b, g->d_sorted);
+                       lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, G);
+    hipLaunchKernelGGL(level_scan_kernel, dim3(levels), dim3(kScanBlock), 0, st, g->d_rank_off, G, g->d_totals);
     NBH_LAUNCH_CHECK();
-    tmp = g->tmp_bytes;
-    NBH_HIP(rocprim::inclusive_scan(g->d_tmp, tmp, level_flags(lvlmask, (unsigned int)ni), g->d_incl, total,
-                                    rocprim::plus<int>(), st));
-    hipLaunchKernelGGL(tree_fill_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       reinterpret_cast<const unsigned int*>(g->d_idx_a), g->d_incl, g->t, g->capacity,
-                       g->d_level_base);
+    const LevelRanks lr{g->d_plane, g->d_rank_off, G};
+    if (fused) {
+      // trees of <= kPrefixMax bodies: every node's monopole from the double-double prefix sums of the sorted bodies,
+      // inside the fill pass (ni + 1 prefix entries: entry ni, the total, is thread ni's "sum before")
+      const int pblocks = ni / kPrefixBlock + 1;
+      dd4* btot = g->d_prefix + g->prefix_cap;
+      dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
+      hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix, btot);
+      hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
+      hipLaunchKernelGGL((tree_fill_kernel<K, true>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->t, g->capacity,
+                         g->d_level_base, g->d_sorted, PrefixSums{g->d_prefix, boff}, g->d_root);
+    } else {
+      hipLaunchKernelGGL((tree_fill_kernel<K, false>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->t, g->capacity,
+                         g->d_level_base, g->d_sorted, PrefixSums{nullptr, nullptr}, g->d_root);
+    }
     NBH_LAUNCH_CHECK();
     return NBODY_HIP_OK;
   };
@@ -1306,22 +1439,7 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   } else {
     if (int rc = topology(static_cast<unsigned int*>(g->d_keys_a), static_cast<unsigned int*>(g->d_keys_b), 0, 30)) return rc;
   }
-  if (ni <= kPrefixMax) {
-    // small tree: every node's monopole from the prefix sums of the sorted bodies (see above)
-    // (ni + 1 entries: entry ni, the total, is thread ni's "sum before")
-    const int pblocks = ni / kPrefixBlock + 1;
-    dd4* btot = g->d_prefix + g->prefix_cap;
-    dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
-    hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix,
-                       btot);
-    hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
-    // the node count is only known on the device: one thread per possible node of a tree of ni bodies
-    const size_t node_bound = std::min((size_t)g->capacity,
-                                       n + (size_t)levels * (n / (size_t)(g->leaf_max + 1) + 1) + 16);
-    hipLaunchKernelGGL(prefix_monopole_kernel, dim3((unsigned)((node_bound + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, st, g->d_level_base, g->max_depth, g->d_sorted, g->d_prefix, boff, g->d_root,
-                       g->t);
-  } else {
+  if (!fused) {
     // monopoles bottom-up: wide levels one launch each, the narrow top in a single workgroup
     const int top = g->max_depth < 4 ? g->max_depth : 4;
     for (int L = g->max_depth; L > top; L--)

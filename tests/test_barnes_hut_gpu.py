@@ -516,6 +516,64 @@ def test_deep_tree_matches_oracle(nb, oracle, ctx, max_depth, leaf_max):
     assert inside[nodes["total_mass"] > 0].all()
 
 
+# the depth a tree reached is reported beyond level 10 (round 2 exported 12 levels only: getMaxDepth saturated)
+def test_max_depth_reported_for_deep_trees(nb, ctx):
+    n = 50000
+    ic = nb.ic.plummer(n, seed=3, a=0.01, rmax=50.0)     # a compact core in a wide box
+    d, _ = to_device(nb, ic)
+    tree = nb.BarnesHutTree(n)
+    tree.build(d)
+    lb = tree.stats()["level_base"]
+    assert len(lb) == 24 and lb[0] == 0 and lb[1] == 1
+    depth = tree.getMaxDepth()
+    assert 10 < depth <= 20, depth
+    assert all(lb[l] < lb[l + 1] for l in range(depth + 1)) and lb[depth + 1] == tree.getNodeCount()
+    tree.setParams(8, 1)
+    tree.build(d)
+    assert tree.getMaxDepth() == 8
+
+
+# A tree that needs more nodes than its arrays hold (nbody_hip_tree_limit_nodes forces it; without the hook the
+# arrays stop at 2^28 - 1 nodes) is CUT where the numbering passes the capacity: the nodes beyond do not exist and
+# their parents are leaves of several bodies, which interact body by body.  Forces stay right: theta = 0 still
+# gives the exact direct sum, theta = 0.5 is at least as close to it as the full tree.  (Round 2 tested the
+# condition on the clamped total, so the fallback was dead and truncated subtrees would have been dropped.)
+@pytest.mark.parametrize("n,limit", [(20000, 9000), (20000, 21000), (120000, 100000), (5000, 16)])
+def test_node_overflow_is_cut_not_wrong(nb, oracle, ctx, n, limit):
+    ic = nb.ic.plummer(n, seed=21)
+    d, h = to_device(nb, ic)
+    eps, G = 0.01, 1.0
+    direct = _direct(nb, d, G, eps)
+    full = nb.BarnesHutTree(n)
+    full.build(d)
+    full.computeForces(d, 0.5, G, eps)
+    a_full = acc_of(d)
+    total_nodes = full.getNodeCount()
+    assert total_nodes > limit
+    tree = nb.BarnesHutTree(n)
+    tree.limitNodes(limit)
+    tree.build(d)
+    assert tree.getNodeCount() == limit
+    assert abs(tree.stats()["root_mass"] - ic["mass"].sum()) < 1e-5
+    tree.computeForces(d, 0.0, G, eps)                    # opens everything: every leaf body by body
+    assert rel_err(acc_of(d), direct).max() < TOL
+    tree.computeForces(d, 0.5, G, eps)
+    a_cut = acc_of(d)
+    e_cut, e_full = rel_err(a_cut, direct), rel_err(a_full, direct)
+    print(f"n = {n}: {total_nodes} nodes cut to {limit}; median error vs direct {np.median(e_cut):.2e} (full tree {np.median(e_full):.2e})")
+    assert np.median(e_cut) <= np.median(e_full) * 1.05 and e_cut.max() < 0.1
+    tree.computeForces(d, 0.5, G, eps)
+    assert np.array_equal(acc_of(d), a_cut)
+    nodes = tree.copyNodesToHost()
+    leaves = nodes[nodes["is_leaf"]]
+    assert leaves["particle_count"].sum() == n and leaves["particle_count"].max() > 1
+    tree.limitNodes(0)                                     # back to the bound: the full tree again
+    tree.build(d)
+    assert tree.getNodeCount() == total_nodes
+    with pytest.raises(nb.ValidationException):
+        tree.limitNodes(5)
+
+
 def test_deep_tree_parameter_errors(nb, ctx):
     tree = nb.BarnesHutTree(1000)
     with pytest.raises(nb.ValidationException):
