@@ -66,6 +66,9 @@ def parse():
                          "(N=1,048,576 two-galaxy, Barnes-Hut theta 0.5, one GPU).  hash/bh report steps/s")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU (RCCL) code path even with one rank (rehearsal)")
+    ap.add_argument("--sharded-host", choices=["cabi", "torch"], default="cabi",
+                    help="Direct on N ranks: cabi = the whole step behind the C ABI (include/nbody_hip_comm.h: RCCL "
+                         "from C++, one call per step); torch = the torch.distributed host (n-body_amd/distributed.py)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--kernel-iters", type=int, default=3, help="launches for the roofline timing")
     return ap.parse_args()
@@ -394,11 +397,41 @@ def main():
         step = lambda: integ.integrate(d, fc, dt)  # noqa: E731
         path = "ParticleSystem-style: Integrator.integrate(ParticleData, DirectForceCalculator)"
     else:
-        sysm = ShardedDirectSystem(ic, G, eps, backend=HipBackend(ctx))
-        sysm.initial_forces()
-        step = lambda: sysm.step(dt)  # noqa: E731
-        path = ("index-range shards; per step one RCCL all-gather of float4 positions and one "
-                "reduce-scatter of float4 accelerations; each shard pair evaluated once (mode %s)" % sysm.mode)
+        csys = None
+        why = ""
+        if a.sharded_host == "cabi" and a.dist_backend == "nccl" and not a.one_device:
+            # the whole step behind the C ABI: RCCL communicator made from C++ (id broadcast over the process
+            # group), drift -> all-gather || own x own -> shard pairs -> point-to-point reaction exchange -> kick
+            try:
+                from nbody_amd.sharded import Comm, ShardedDirect
+                comm = Comm.from_torch_distributed(local_rank)
+                csys = ShardedDirect(comm, n, G, eps)
+                csys.set_state(ic)
+                csys.forces()
+                csys.synchronize()
+            except Exception as e:  # every rank runs the same build: all fall back alike
+                why = f" (C-ABI host unavailable: {type(e).__name__}: {e})"
+                csys = None
+            ok = torch.tensor([1 if csys is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                csys = None
+        if csys is not None:
+            step = lambda: csys.step(dt, 1)  # noqa: E731
+            path = ("C ABI (nbody_hip_sharded_direct_step): index-range shards; per step one RCCL all-gather of float4 "
+                    "positions overlapped with own x own, each shard pair evaluated once by one rank, reaction blocks "
+                    "sent point-to-point to their owners, fixed-order sum fused with the kick")
+            inner_barrier = barrier
+
+            def barrier():  # noqa: F811  (the system's own streams first)
+                csys.synchronize()
+                inner_barrier()
+        else:
+            sysm = ShardedDirectSystem(ic, G, eps, backend=HipBackend(ctx))
+            sysm.initial_forces()
+            step = lambda: sysm.step(dt)  # noqa: E731
+            path = ("torch.distributed host: index-range shards; per step one RCCL all-gather of float4 positions and one "
+                    "reduce-scatter of float4 accelerations; each shard pair evaluated once (mode %s)%s" % (sysm.mode, why))
 
     for _ in range(a.warmup):
         step()
@@ -425,6 +458,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"plummer_N{n}_direct_n2_velocity_verlet", "bodies": n,
                        "eps": eps, "dt": dt, "G": G, "seed": 42, "path": path, "deterministic": not a.atomics,
+                       "deterministic_mode": ctx.directInfo()["deterministic_mode"],
                        "sharding": f"targets_by_index_range_x{world}"},
         }
         # --- roofline of the dominant kernel, timed live with HIP events on the launch stream
@@ -433,12 +467,13 @@ def main():
         eps2 = float(np.float32(eps) * np.float32(eps))
         if world == 1:
             # the step's force evaluation: all pairs of one body set -> nbh::direct_sym_kernel
-            r = a.tpl if a.tpl in (2, 4, 6, 8, 16) else (16 if n >= 786432 else 8 if n >= 28000 else 4)  # direct_sym.hip sym_R
-            det = not getattr(a, "atomics", False)  # deterministic slot planes are the default (include/nbody_hip.h)
+            # which kernel that is comes from the library itself (nbody_hip_direct_info), not from a copy of its rules
+            info = ctx.directInfo(n, eps2)
+            det = info["kernel"] == 2
             eqm = float(np.ptp(ic['mass'])) == 0.0
-            r_run = r if eqm or not det or r != 16 or a.tpl else 8  # general masses + slots: 8 bodies per lane
+            r_run = info["bodies_per_lane_equal"] if eqm else info["bodies_per_lane_general"]
             kname = (f"nbh::direct_sym_kernel<{r_run},false,{'true' if eqm else 'false'},{'true' if det else 'false'}>"
-                     if n >= 12288 and a.variant in (-1, 3) else "nbh::direct_kernel (one-sided)")
+                     if info["kernel"] > 0 else "nbh::direct_kernel (one-sided)")
             ms = nb.time_direct_packed(ctx, p, p, G, eps2, a.kernel_iters)
             pairs = float(n) * n
             alg_bytes = 16.0 * n + 16.0 * n
@@ -446,7 +481,7 @@ def main():
             # the step's dominant launch: own shard x one remote shard, action + reaction
             S = (n + world - 1) // world
             r = a.tpl if a.tpl in (2, 4, 6, 8, 16) else (16 if S >= 49152 else 8 if S >= 16384 else 4)
-            kname = f"nbh::direct_sym_kernel<{r},true,...> (shard pair)"
+            kname = f"nbh::direct_sym_kernel<{r},true,...,{'true' if not a.atomics else 'false'}> (shard pair)"
             A, B = p[:S].contiguous(), p[S:2 * S].contiguous()
             accA, accB = torch.zeros_like(A), torch.zeros_like(B)
             nb.direct_forces_pair_packed(ctx, A, B, G, eps2, accA, accB)
@@ -466,6 +501,7 @@ def main():
             "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
             "traffic": read_pmc_traffic() if world == 1 else None,
             "launch_ms": ms, "pairs_per_launch": pairs, "flop_per_pair": FLOP_PER_PAIR,
+            "direct_info": (ctx.directInfo(n, eps2) if world == 1 else None),
             "pair_interactions_per_s_kernel": pairs / (ms * 1e-3),
             "hbm": {"algorithmic_bytes": alg_bytes, "achieved": alg_bytes / (ms * 1e-3) / 1e9,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -487,7 +523,7 @@ def main():
             ms_g = nb.time_direct_packed(ctx, pg, pg, G, eps2, a.kernel_iters)
             ach_g = FLOP_PER_PAIR * float(n) * n / (ms_g * 1e-3) / 1e12
             out["roofline"]["general_mass"] = {
-                "kernel": (f"nbh::direct_sym_kernel<{12 if (det and r == 16 and not a.tpl) else r},false,false,"
+                "kernel": (f"nbh::direct_sym_kernel<{info['bodies_per_lane_general']},false,false,"
                            f"{'true' if det else 'false'}>"), "launch_ms": ms_g, "achieved": ach_g,
                 "frac": ach_g / PEAK_FP32_VALU_TFLOPS, "pair_interactions_per_s_kernel": float(n) * n / (ms_g * 1e-3),
                 "note": "same positions, masses multiplied by U[0.75, 1.25)"}

@@ -330,28 +330,36 @@ __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict_
 // totals[L] <- nodes of the level
 constexpr int kScanBlock = 1024;
 __global__ __launch_bounds__(kScanBlock) void level_scan_kernel(int* __restrict__ off, int G, int* __restrict__ totals) {
-  __shared__ int part[kScanBlock];
-  const int L = blockIdx.x, tid = threadIdx.x;
+  constexpr int NW = kScanBlock / 64;
+  __shared__ int wsum[NW];
+  const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int* o = off + (size_t)L * G;
-  const int per = (G + kScanBlock - 1) / kScanBlock;
-  const int g0 = min(G, tid * per), g1 = min(G, g0 + per);
+  // wave wv owns the contiguous chunk [c0, c1) (a multiple of 64 long): coalesced loads, shuffle scans
+  const int per = ((G + NW - 1) / NW + 63) & ~63;
+  const int c0 = min(G, wv * per), c1 = min(G, c0 + per);
   int sum = 0;
-  for (int g = g0; g < g1; g++) sum += o[g];
-  part[tid] = sum;
+  for (int g = c0 + lane; g < c1; g += 64) sum += o[g];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) wsum[wv] = sum;
   __syncthreads();
-  for (int d = 1; d < kScanBlock; d <<= 1) {  // inclusive scan of the chunk sums
-    const int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int run = 0, total = 0;
+  for (int k = 0; k < NW; k++) {
+    if (k < wv) run += wsum[k];
+    total += wsum[k];
   }
-  int run = part[tid] - sum;
-  for (int g = g0; g < g1; g++) {
-    const int c = o[g];
-    o[g] = run;
-    run += c;
+  for (int g = c0; g < c1; g += 64) {
+    const int c = g + lane < c1 ? o[g + lane] : 0;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += up;
+    }
+    if (g + lane < c1) o[g + lane] = run + inc - c;
+    run += __shfl(inc, 63, 64);
   }
-  if (tid == kScanBlock - 1) totals[L] = part[tid];
+  if (tid == 0) totals[L] = total;
 }
 
 // One thread per BODY: it fills the nodes this body heads (the set bits of its level mask; 1.3 nodes per
@@ -676,6 +684,28 @@ __device__ __forceinline__ double4 prefix_monopole(const PrefixSums& ps, const f
     s[c] = hi.hi[c] + hi.lo[c];
   }
   return s[3] > 0.0 ? make_double4(s[0] / s[3], s[1] / s[3], s[2] / s[3], s[3]) : make_double4(0.0, 0.0, 0.0, 0.0);
+}
+
+// one thread per NODE (the fill pass is one thread per body with 1..21 nodes each: fusing this arithmetic into it
+// was measured slower, 144 us against 60 + 49 at N = 2^20 -- the per-body trip counts diverge)
+__global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __restrict__ level_base, int max_depth,
+                                                                 const float4* __restrict__ sorted, PrefixSums ps,
+                                                                 const TreeRoot* __restrict__ root, TreeArrays t) {
+  const int nid = blockIdx.x * kBlock + threadIdx.x;
+  if (nid >= level_base[max_depth + 1]) return;
+  int level = 0;
+  while (level < max_depth && nid >= level_base[level + 1]) level++;
+  const int first = t.first[nid], last = t.last[nid], cnt = last - first;
+  const int c0 = t.child0[nid];
+  const double4 mono = prefix_monopole(ps, sorted, first, last);
+  const float h = ldexpf(root->half, -level);
+  const float size = 2.0f * h;  // :168
+  NodeRec r;
+  r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
+  r.size2 = size * size;
+  r.first = first; r.count = cnt;
+  r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
+  store_node(t, nid, level, r);
 }
 
 constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; [66..130] by lanes accepting
@@ -1411,22 +1441,9 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     hipLaunchKernelGGL(level_scan_kernel, dim3(levels), dim3(kScanBlock), 0, st, g->d_rank_off, G, g->d_totals);
     NBH_LAUNCH_CHECK();
     const LevelRanks lr{g->d_plane, g->d_rank_off, G};
-    if (fused) {
-      // trees of <= kPrefixMax bodies: every node's monopole from the double-double prefix sums of the sorted bodies,
-      // inside the fill pass (ni + 1 prefix entries: entry ni, the total, is thread ni's "sum before")
-      const int pblocks = ni / kPrefixBlock + 1;
-      dd4* btot = g->d_prefix + g->prefix_cap;
-      dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
-      hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix, btot);
-      hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
-      hipLaunchKernelGGL((tree_fill_kernel<K, true>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->t, g->capacity,
-                         g->d_level_base, g->d_sorted, PrefixSums{g->d_prefix, boff}, g->d_root);
-    } else {
-      hipLaunchKernelGGL((tree_fill_kernel<K, false>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->t, g->capacity,
-                         g->d_level_base, g->d_sorted, PrefixSums{nullptr, nullptr}, g->d_root);
-    }
+    hipLaunchKernelGGL((tree_fill_kernel<K, false>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                       reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->t, g->capacity,
+                       g->d_level_base, g->d_sorted, PrefixSums{nullptr, nullptr}, g->d_root);
     NBH_LAUNCH_CHECK();
     return NBODY_HIP_OK;
   };
@@ -1439,7 +1456,20 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   } else {
     if (int rc = topology(static_cast<unsigned int*>(g->d_keys_a), static_cast<unsigned int*>(g->d_keys_b), 0, 30)) return rc;
   }
-  if (!fused) {
+  if (fused) {
+    // trees of <= kPrefixMax bodies: every node's monopole from the double-double prefix sums of the sorted bodies
+    // (ni + 1 prefix entries: entry ni, the total, is thread ni's "sum before")
+    const int pblocks = ni / kPrefixBlock + 1;
+    dd4* btot = g->d_prefix + g->prefix_cap;
+    dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
+    hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix, btot);
+    hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
+    // the node count is only known on the device: one thread per possible node of a tree of ni bodies
+    const size_t node_bound = std::min((size_t)g->capacity,
+                                       n + (size_t)levels * (n / (size_t)(g->leaf_max + 1) + 1) + 16);
+    hipLaunchKernelGGL(prefix_monopole_kernel, dim3((unsigned)((node_bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       g->d_level_base, g->max_depth, g->d_sorted, PrefixSums{g->d_prefix, boff}, g->d_root, g->t);
+  } else {
     // monopoles bottom-up: wide levels one launch each, the narrow top in a single workgroup
     const int top = g->max_depth < 4 ? g->max_depth : 4;
     for (int L = g->max_depth; L > top; L--)

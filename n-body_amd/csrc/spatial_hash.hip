@@ -29,11 +29,24 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/zip_iterator.hpp>
 
 #include "common.h"
 
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                             rocprim::default_config, nbh::kSortMergeLimit>;
+// Binning = ONE stable sort by cell id that carries the bodies along: the values are (float4 body, original
+// index) pairs -- a zip of the packed bodies with a counting iterator on the way in, of the cell-ordered body array
+// and the index array on the way out -- so the separate gather pass of round 2 (87 us at 4.2 M bodies: a random
+// 16-byte read per body) is gone, and with 10-bit digits the 19 cell-id bits of BASELINE config 5 are two Onesweep
+// passes instead of three.
+#ifndef NBH_HASH_RADIX_BITS
+#define NBH_HASH_RADIX_BITS 10
+#endif
+using SortConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<1024, 8>,
+                                        NBH_HASH_RADIX_BITS, rocprim::block_radix_rank_algorithm::match>,
+    nbh::kSortMergeLimit>;
 
 namespace nbh {
 
@@ -238,8 +251,7 @@ __device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim
 __global__ __launch_bounds__(kBlock) void assign_cells_kernel(const float4* __restrict__ posm, int n,
                                                               const GridInfo* __restrict__ info,
                                                               float cell,
-                                                              unsigned int* __restrict__ keys,
-                                                              int* __restrict__ idx) {
+                                                              unsigned int* __restrict__ keys) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 p = posm[i];
@@ -248,15 +260,6 @@ __global__ __launch_bounds__(kBlock) void assign_cells_kernel(const float4* __re
   const int cy = cell_coord(p.y, info->bmin[1], cell, gy);
   const int cz = cell_coord(p.z, info->bmin[2], cell, gz);
   keys[i] = (unsigned int)(cx + cy * gx + cz * gx * gy);
-  idx[i] = i;
-}
-
-// physical reorder into cell order
-__global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const float4* __restrict__ posm,
-                                                               const int* __restrict__ idx, int n,
-                                                               float4* __restrict__ out) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k < n) out[k] = posm[idx[k]];
 }
 
 // Per-cell start array: cell_lb[c - base] = number of bodies whose cell id is below c (= sorted position of the
@@ -539,7 +542,11 @@ struct CellGridView {
 
 // Targets: the bodies of grid `tg` in the cells [cell_first, cell_end); sources: grid `sg` (the same grid,
 // or -- sharded path -- the halo layers received from the neighbouring ranks).  ACCUM adds to acc4.
-template <bool GUARD, int R>
+// HALF (timing probe only, nbody_hip_grid_tuning kernel 5): the window is cut to the half shell -- the cell itself
+// and its 13 "forward" neighbours -- and NO reactions are applied, so the output is not the force.  Its time is a
+// lower bound for any Newton's-third-law form of this kernel (half the candidate pairs, reaction arithmetic and
+// reaction traffic free); DESIGN.md section 4.4 sets it against the cost of deterministic reaction slots.
+template <bool GUARD, int R, bool HALF = false>
 __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
@@ -571,9 +578,9 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       if (r < 9) {
         const int cx = (int)(cell % gx), cy = (int)((cell / gx) % gy), cz = (int)(cell / ((long long)gx * gy));
         const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
-        if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+        if (yy >= 0 && yy < gy && zz >= 0 && zz < gz && !(HALF && r < 4)) {
           const long long base = ((long long)zz * gy + yy) * gx;
-          vseg0 = sgv.lower(base + max(cx - 1, 0));
+          vseg0 = sgv.lower(base + max(cx - ((HALF && r == 4) ? 0 : 1), 0));
           vlen = sgv.lower(base + min(cx + 2, gx)) - vseg0;
         }
       } else if (r < 11) {
@@ -738,6 +745,15 @@ __global__ void bbox_decode_kernel(const unsigned int* __restrict__ enc, float* 
 
 using namespace nbh;
 
+// stable radix sort of the cell ids carrying (body, original index) along; temp == nullptr: size query
+static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned int* keys_in, unsigned int* keys_out,
+                                      const float4* bodies_in, float4* bodies_out, int* idx_out, size_t n, int bits,
+                                      hipStream_t st) {
+  auto vin = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_in, rocprim::make_counting_iterator<int>(0)));
+  auto vout = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_out, idx_out));
+  return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vin, vout, n, 0, bits, st);
+}
+
 struct nbody_hip_grid {
   nbody_hip_ctx* ctx = nullptr;
   size_t max_particles = 0;
@@ -748,7 +764,7 @@ struct nbody_hip_grid {
   GridInfo* h_info = nullptr;          // pinned
   GridInfo* h_info_dev = nullptr;      // the device's address of h_info (null: not mapped, copy instead)
   unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
-  int *d_idx_a = nullptr, *d_idx_b = nullptr;
+  int* d_idx_b = nullptr;              // cell order -> original body index
   float4* d_sorted = nullptr;
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -759,7 +775,8 @@ struct nbody_hip_grid {
   bool lb_valid = false;
   long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
   int slab_z0 = 0, slab_nz = 0;         // packed builds: z layers this grid holds (nz <= 0: all)
-  int tune_kernel = 0;                 // 0 automatic, 1 cell-run kernel, 2 / 3 / 4 wave-per-cell kernel with R = 1 / 2 / 4
+  int tune_kernel = 0;                 // 0 automatic, 1 cell-run kernel, 2 / 3 / 4 wave-per-cell kernel with R = 1 / 2 / 4,
+                                       // 5 = half-shell TIMING PROBE (not forces)
   bool ranges_valid = false;
   // host mirror of the last build
   GridInfo info{};
@@ -769,7 +786,7 @@ struct nbody_hip_grid {
 static void grid_release(nbody_hip_grid* g) {
   if (!g) return;
   (void)hipFree(g->d_enc); (void)hipFree(g->d_info); (void)hipFree(g->d_keys_a);
-  (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_a); (void)hipFree(g->d_idx_b);
+  (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_b);
   (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_cell_start);
   (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb);
   if (g->h_info) (void)hipHostFree(g->h_info);
@@ -799,13 +816,11 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_keys_a), n * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_keys_b), n * sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_idx_a), n * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_idx_b), n * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_sorted), n * sizeof(float4));
   if (e == hipSuccess) {
     size_t tmp = 0;
-    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a, g->d_idx_b, n,
-                                  0, 32, ctx->stream);
+    e = sort_bodies_by_cell(nullptr, tmp, g->d_keys_a, g->d_keys_b, g->d_sorted, g->d_sorted, g->d_idx_b, n, 32, ctx->stream);
     if (e == hipSuccess) {
       g->sort_tmp_bytes = tmp;
       e = hipMalloc(&g->d_sort_tmp, tmp > 0 ? tmp : 16);
@@ -837,7 +852,7 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
 }
 extern "C" int nbody_hip_grid_tuning(nbody_hip_grid* g, int kernel) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
-  if (kernel < 0 || kernel > 4) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..4");
+  if (kernel < 0 || kernel > 5) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..5");
   g->tune_kernel = kernel;
   return NBODY_HIP_OK;
 }
@@ -896,11 +911,12 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   }
   hipLaunchKernelGGL(assign_cells_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_info,
-                     g->cell_size, g->d_keys_a, g->d_idx_a);
+                     g->cell_size, g->d_keys_a);
   NBH_LAUNCH_CHECK();
   size_t tmp = g->sort_tmp_bytes;
-  NBH_HIP(rocprim::radix_sort_pairs<SortConfig>(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, g->d_idx_a,
-                                    g->d_idx_b, n, 0, bits_for(g->info.total), st));
+  // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
+  NBH_HIP(sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n,
+                              bits_for(g->info.total), st));
   g->lb_valid = false;
   {
     // cells the per-cell start array covers: the whole grid, or the z layers of this rank's slab
@@ -923,7 +939,6 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)cap * sizeof(int)));
       g->lb_capacity = cap;
     }
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, g->d_idx_b, ni, g->d_sorted);
     if (dense)
       hipLaunchKernelGGL(cell_lb_kernel, dim3((unsigned)((count + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, ni, (int)base, (int)count, g->d_cell_lb);
@@ -1000,7 +1015,10 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
   hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,    \
                      ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, \
                      az, acc4, accumulate)
-  if (kern == 2)      { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
+  if (kern == 5) {  // timing probe (see the kernel): not forces
+    hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, ctx->stream, tv,
+                       sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az, acc4, accumulate);
+  } else if (kern == 2) { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
   else if (kern == 4) { if (guard) NBH_CELL_LAUNCH(true, 4); else NBH_CELL_LAUNCH(false, 4); }
   else                { if (guard) NBH_CELL_LAUNCH(true, 2); else NBH_CELL_LAUNCH(false, 2); }
 #undef NBH_CELL_LAUNCH
