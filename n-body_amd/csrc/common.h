@@ -127,8 +127,12 @@ struct DirectPlan {
   size_t bytes = 0;               // workspace the call needs
   size_t det_bytes_wanted = 0;    // what the slot planes would need (also when they were refused)
 };
-constexpr int kDetGenR = 12;      // bodies per lane of the general-mass instantiation in deterministic mode at sizes
-                                  // where the equal-mass one takes 16
+#ifndef NBH_DET_GEN_R
+#define NBH_DET_GEN_R 16
+#endif
+constexpr int kDetGenR = NBH_DET_GEN_R;  // bodies per lane of the general-mass instantiation in deterministic mode at sizes
+                                         // where the equal-mass one takes 16 (round 2: 12 -- the slot kernel spilled into
+                                         // AGPRs at 16; with the single loop body of round 3 it does not)
 SymShape sym_shape(const nbody_hip_ctx* ctx, size_t n, int R);
 DirectPlan direct_plan(const nbody_hip_ctx* ctx, size_t n, bool query_device);
 

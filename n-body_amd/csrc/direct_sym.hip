@@ -236,7 +236,16 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
         jx = wave_rot1(jx); jy = wave_rot1(jy); jz = wave_rot1(jz); jm = wave_rot1(jm);
       }
     };
-    if (react) steps(std::true_type{}); else steps(std::false_type{});
+    if constexpr (R >= 12) {
+      // ONE loop body at 12 / 16 bodies per lane: the diagonal superblock pair (d = 0: one partner in D + 1, i.e.
+      // 0.8 % of the chunks at N = 2^20) computes its reactions too and drops them at the flush.  Two instantiations
+      // of the 64-step loop cost registers: the general-mass slot kernel at R = 16 needed 256 VGPRs + 29 AGPR copies
+      // (191 ms at N = 2^20, which is why round 2 ran it at R = 12); with one body it fits 246.
+      (void)react;
+      steps(std::true_type{});
+    } else {
+      if (react) steps(std::true_type{}); else steps(std::false_type{});
+    }
     // after 64 one-lane rotations every J body (and its reaction sum) is back in its home lane
     slab[q & 1][w][0][lane] = hjx; slab[q & 1][w][1][lane] = hjy; slab[q & 1][w][2][lane] = hjz;
     if ((q & 3) == 3 || q == nchunks - 1) {  // fold the fp32 sums of <= 256 sources into fp64
@@ -452,7 +461,7 @@ DirectPlan direct_plan(const nbody_hip_ctx* ctx, size_t n, bool query_device) {
     // general masses at 16 bodies per lane: the slot stores push the kernel past the 256 architectural registers
     // (191 ms against 170 ms with atomics at N = 2^20); 12 bodies per lane (78 KiB of LDS = two workgroups per CU)
     // run it in 172 ms where 8 take 177 (tools/direct_det_probe.py, same box)
-    SymShape gen = (p.eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, kDetGenR) : p.eq;
+    SymShape gen = (kDetGenR != 16 && p.eq.R == 16 && ctx->tune_tpl == 0) ? sym_shape(ctx, n, kDetGenR) : p.eq;
     size_t need = p.eq.det_bytes() > gen.det_bytes() ? p.eq.det_bytes() : gen.det_bytes();
     bool ok = query_device ? det_budget_allows(ctx, need, nullptr) : need <= ctx->det_budget;
     if (!ok && gen.R != p.eq.R) {  // the general-mass shape has more slots: try with the common shape

@@ -242,6 +242,12 @@ __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cel
   }
 }
 
+// grid geometry decided on the host (explicit bounds: the sharded path): the record travels as a kernel argument,
+// so there is no pinned staging buffer to protect and the build needs no stream synchronisation
+__global__ void grid_info_set_kernel(GridInfo gi, GridInfo* __restrict__ info) {
+  if (threadIdx.x == 0) *info = gi;
+}
+
 __device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim) {
   int c = (int)floorf((p - lo) / cell);
   return min(max(c, 0), dim - 1);
@@ -877,8 +883,7 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
   if (bounds) {
-    GridInfo& gi = *g->h_info;
-    NBH_HIP(hipStreamSynchronize(st));  // h_info may still be in flight from the previous build
+    GridInfo gi{};
     long long total = 1;
     for (int a = 0; a < 3; a++) {
       gi.bmin[a] = bounds[a];
@@ -890,7 +895,8 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     g->info = gi;
     if (g->info.total > 100000000LL)
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
-    NBH_HIP(hipMemcpyAsync(g->d_info, g->h_info, sizeof(GridInfo), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(grid_info_set_kernel, dim3(1), dim3(64), 0, st, gi, g->d_info);
+    NBH_LAUNCH_CHECK();
   } else {
     if (soa && drift_dt) {
       if (int rc = launch_drift_pack_bbox(ctx, const_cast<nbody_particle_data*>(soa), *drift_dt, posm, g->d_enc)) return rc;

@@ -562,14 +562,21 @@ class ShardedHashSystem:
             halo = torch.empty((sum(r_split), 4), dtype=torch.float32, device=dev)
             work = dist.all_to_all_single(halo, out, output_split_sizes=r_split, input_split_sizes=s_split,
                                           group=self.group, async_op=True)
-        # own x own while the halo layers are in flight
+        # own x own while the halo layers are in flight -- if both grids are dense enough for the per-cell start
+        # arrays of the two-grid kernel (the library's test: cells covered <= 4 bodies + 4096).  Decided HERE, from
+        # the layer histogram, before anything is launched: a grid that turns out too sparse after own x own has
+        # run would throw that work away.
         acc_new = self._buf["acc2"][:n_new]
-        two_grid = True
-        if n_new:
+        n_halo = 0 if halo is None else int(halo.shape[0])
+        layer_cells = gx * gy
+        z0h, z1h = max(z_lo - 1, 0), min(z_hi + 1, gz)
+        two_grid = ((z_hi - z_lo) * layer_cells <= 4 * n_new + 4096 and
+                    (n_halo == 0 or (z1h - z0h) * layer_cells <= 4 * n_halo + 4096))
+        if n_new and two_grid:
             two_grid = b.grid_forces("own", "own", z_lo, z_hi - z_lo, self.cutoff, self.G, self.eps, acc_new, False)
         if work is not None:
             work.wait()
-        self.halo_bodies = 0 if halo is None else int(halo.shape[0])
+        self.halo_bodies = n_halo
         if n_new and two_grid and self.halo_bodies:
             z0, z1 = max(z_lo - 1, 0), min(z_hi + 1, gz)
             b.grid_build("halo", halo, bounds, self.cell, z0, z1 - z0)

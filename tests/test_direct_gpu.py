@@ -500,7 +500,7 @@ def test_direct_info_and_workspace_policy(nb, ctx):
     pb_, ps_ = packed(nb.ic.plummer(big, seed=1)), packed(nb.ic.plummer(small, seed=2))
     plan = ctx.directInfo(big, 1e-6)
     assert plan["deterministic_mode"] == 1 and plan["kernel"] == 2 and plan["kernel_name"] == "symmetric+slots"
-    assert plan["bodies_per_lane_equal"] == 16 and plan["bodies_per_lane_general"] == 12
+    assert plan["bodies_per_lane_equal"] == 16 and plan["bodies_per_lane_general"] == 16
     nb.direct_forces_packed(ctx, pb_, pb_, 1.0, 1e-6)
     held = ctx.directInfo()["workspace_bytes_held"]
     assert held >= plan["workspace_bytes_needed"] > 100 << 20
