@@ -236,11 +236,13 @@ __global__ __launch_bounds__(kBlock) NBH_SYM_ATTR void direct_sym_kernel(const f
         jx = wave_rot1(jx); jy = wave_rot1(jy); jz = wave_rot1(jz); jm = wave_rot1(jm);
       }
     };
-    if constexpr (R >= 12) {
-      // ONE loop body at 12 / 16 bodies per lane: the diagonal superblock pair (d = 0: one partner in D + 1, i.e.
-      // 0.8 % of the chunks at N = 2^20) computes its reactions too and drops them at the flush.  Two instantiations
-      // of the 64-step loop cost registers: the general-mass slot kernel at R = 16 needed 256 VGPRs + 29 AGPR copies
-      // (191 ms at N = 2^20, which is why round 2 ran it at R = 12); with one body it fits 246.
+    if constexpr (R >= 12 && !EQM) {
+      // GENERAL masses at 12 / 16 bodies per lane: ONE loop body -- the diagonal superblock pair (d = 0: one partner
+      // in D + 1, i.e. 0.8 % of the chunks at N = 2^20) computes its reactions too and drops them at the flush.  Two
+      // instantiations of the 64-step loop cost registers: the slot kernel at R = 16 needed 256 VGPRs + 29 AGPR
+      // copies (190 ms at N = 2^20, which is why round 2 ran it at R = 12); with one body it fits 246 (171.5 ms).
+      // The equal-mass kernel keeps both bodies: with one it needs fewer registers (226) but the schedule the
+      // compiler then picks is slower (R = 16: 170 ms against 158, measured, tools/direct_det_probe.py).
       (void)react;
       steps(std::true_type{});
     } else {
