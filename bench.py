@@ -137,6 +137,22 @@ def cpu_baseline(ic, eps, seconds):
                       f"(oracle mode 0), OpenMP over targets, {dt:.1f} s"}
 
 
+def read_pmc_issue(name):
+    """Instruction-issue view of a kernel (VALU busy cycles / SIMD cycles, scalar-unit busy, mean resident waves) from
+    the committed counter summary of the SAME command (tools/profile_step.sh -> tools/pmc_step_summarise.py); PMC
+    passes serialise the kernels, so they are separate runs -- never collected inside the timed bench."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+        out = dict(d["issue"])
+        out.update({"mean_waves_per_simd": d.get("mean_waves_per_simd"), "valu_per_wave": d["per_wave"].get("VALU"),
+                    "salu_per_wave": d["per_wave"].get("SALU"), "launch_ms_profiled": d.get("launch_ms_profiled"),
+                    "source": "profiles/" + name})
+        return out
+    except Exception:
+        return None
+
+
 def read_pmc_traffic():
     """HBM bytes per direct_kernel launch from the committed rocprofv3 PMC summary, if any."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -301,6 +317,7 @@ def other_roofline(a, nb, ps, torch, workload):
         return {"kernel": kernel, "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0,
                 "unit": "GB/s", "frac": nbytes / t / 8e12, "traffic": None, "avg_kernel_ms": t * 1e3,
                 "node_visits_per_s": visits / t, "nodes": st["node_count"],
+                "issue": read_pmc_issue("r03_pmc_bh_pair_kernel.json"),
                 "note": "32 B per node record a wave fetches (scalar cache / L2, mostly not HBM) + 16 B per body; "
                         "the walk is latency- and issue-bound, see DESIGN.md 4.5"}
     cs, ce, _, _ = grid.copyCellDataToHost()
@@ -318,6 +335,7 @@ def other_roofline(a, nb, ps, torch, workload):
             "bound": "valu", "achieved": flops / t / 1e12, "peak": 157.3,
             "unit": "TFLOP/s", "frac": flops / t / 157.3e12, "traffic": None, "avg_kernel_ms": t * 1e3,
             "candidate_pairs_per_s": pairs / t, "gather_bytes_per_s": 16.0 * pairs / t,
+            "issue": read_pmc_issue("r03_pmc_hash_cell_kernel.json"),
             "note": "20 flop per candidate pair (distance + cutoff test + force); 16 B per candidate pair is the "
                     "SURVEY 8d gather figure, served from LDS tiles (HBM traffic is 28 B per body)"}
 
@@ -500,6 +518,7 @@ def main():
             "kernel": kname, "bound": "valu", "achieved": achieved,
             "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
             "traffic": read_pmc_traffic() if world == 1 else None,
+            "traffic_source": "profiles/pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over this command",
             "launch_ms": ms, "pairs_per_launch": pairs, "flop_per_pair": FLOP_PER_PAIR,
             "direct_info": (ctx.directInfo(n, eps2) if world == 1 else None),
             "pair_interactions_per_s_kernel": pairs / (ms * 1e-3),

@@ -571,28 +571,46 @@ int direct_symmetric(nbody_hip_ctx* ctx, const float4* posm, size_t n, float G, 
 int direct_symmetric_pair(nbody_hip_ctx* ctx, const float4* pi, size_t ni, const float4* pj, size_t nj,
                           float G, float eps2, float4* acc_i, int accumulate_i, float4* acc_j,
                           int accumulate_j) {
-  const int R = sym_R(ctx, ni < nj ? ni : nj, true);
-  const int S = kBlock * R;
-  const int NBI = (int)((ni + S - 1) / S), NBJ = (int)((nj + S - 1) / S);
-  const int total = NBJ * (S / 64);
-  int splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * kSymBlocksPerCU + NBI - 1) / NBI;
-  if (splits < 1) splits = 1;
-  int per = (total + splits - 1) / splits;
-  if (per < kSymMinChunks) per = kSymMinChunks;
-  if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);
-  splits = (total + per - 1) / per;
-  const size_t plane_i = (size_t)NBI * S, plane_j = (size_t)NBJ * S;
-  const size_t det_i = align256((size_t)splits * 3 * plane_i * sizeof(double));
-  const size_t det_j = (size_t)NBI * 3 * plane_j * sizeof(float);
+  // launch shape; the deterministic form has its own: 8 bodies per lane and half as many workgroups per CU -- every
+  // split owns an fp64 I-side slot per body (24 B x splits x n_i written and read back), so fewer, longer splits pay:
+  // 131,072 x 131,072 bodies: 5.04 ms against 5.47 at 16 bodies per lane / 128 splits (atomics: 4.95;
+  // tools/pair_det_probe.py)
+  int R = 0, NBI = 0, NBJ = 0, per = 0, splits = 0;
+  size_t plane_i = 0, plane_j = 0, det_i = 0, det_j = 0;
+  auto shape = [&](bool det_form) {
+    const size_t nmin = ni < nj ? ni : nj;
+    R = sym_R(ctx, nmin, true);
+    if (det_form && ctx->tune_tpl == 0 && R > 8) R = 8;
+    const int S = kBlock * R;
+    NBI = (int)((ni + S - 1) / S);
+    NBJ = (int)((nj + S - 1) / S);
+    const int total = NBJ * (S / 64);
+    const int per_cu = det_form ? kSymBlocksPerCU / 2 : kSymBlocksPerCU;
+    splits = ctx->tune_splits > 0 ? ctx->tune_splits : (kNumCU * per_cu + NBI - 1) / NBI;
+    if (splits < 1) splits = 1;
+    per = (total + splits - 1) / splits;
+    if (per < kSymMinChunks) per = kSymMinChunks;
+    if (per > S / 64) per = (per + S / 64 - 1) / (S / 64) * (S / 64);
+    splits = (total + per - 1) / per;
+    plane_i = (size_t)NBI * S;
+    plane_j = (size_t)NBJ * S;
+    det_i = align256((size_t)splits * 3 * plane_i * sizeof(double));
+    det_j = (size_t)NBI * 3 * plane_j * sizeof(float);
+  };
+  shape(ctx->deterministic != 0);
   bool det = ctx->deterministic != 0 && det_budget_allows(ctx, det_i + det_j, nullptr);
   if (ctx->deterministic == 2 && !det)
     return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "deterministic Direct sums were required but their slot planes (%zu bytes) "
                     "exceed the budget", det_i + det_j);
-  const size_t bi = align256(plane_i * 3 * sizeof(double)), bj = plane_j * 3 * sizeof(double);
+  if (!det) shape(false);
+  size_t bi = align256(plane_i * 3 * sizeof(double)), bj = plane_j * 3 * sizeof(double);
   int rc = ctx->partial.reserve(det ? det_i + det_j : bi + bj);
   if (rc != NBODY_HIP_OK && det && ctx->deterministic != 2) {
     (void)hipGetLastError();
     det = false;
+    shape(false);
+    bi = align256(plane_i * 3 * sizeof(double));
+    bj = plane_j * 3 * sizeof(double);
     rc = ctx->partial.reserve(bi + bj);
   }
   if (rc != NBODY_HIP_OK) return rc;

@@ -22,9 +22,9 @@ pg[:, 3] *= torch.from_numpy((0.75 + 0.5 * np.random.default_rng(7).random(2 * S
 for name, q in (("equal", p), ("general", pg)):
     a, b = q[:S].contiguous(), q[S:].contiguous()
     acc_a, acc_b = torch.zeros_like(a), torch.zeros_like(b)
-    for tpl in (8, 16):
-        for det in (1, 0):
-            ctx.tuning(-1, tpl, 0)
+    for tpl, det, splits in ((8, 1, 0), (8, 0, 0), (16, 1, 0), (16, 0, 0), (16, 1, 96), (16, 1, 64), (16, 1, 48), (16, 1, 32), (16, 0, 64), (8, 1, 64), (8, 1, 32)):
+        if True:
+            ctx.tuning(-1, tpl, splits)
             ctx.deterministic(det)
             nb.direct_forces_pair_packed(ctx, a, b, 1.0, 1e-6, acc_a, acc_b)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,6 +33,6 @@ for name, q in (("equal", p), ("general", pg)):
                 nb.direct_forces_pair_packed(ctx, a, b, 1.0, 1e-6, acc_a, acc_b)
             e1.record()
             e1.synchronize()
-            print(f"pair {S} x {S} {name} masses R={tpl} deterministic={det}: {e0.elapsed_time(e1) / 5:.3f} ms", flush=True)
+            print(f"pair {S} x {S} {name} masses R={tpl} deterministic={det} splits={splits or 'auto'}: {e0.elapsed_time(e1) / 5:.3f} ms", flush=True)
 ctx.tuning()
 ctx.deterministic(1)
