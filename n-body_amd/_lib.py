@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnbody_hip.so")
+# NBODY_HIP_LIB: another build of the same library (kernel experiments: tools/ build variants into gpurun_out/)
+LIB_PATH = os.environ.get("NBODY_HIP_LIB") or os.path.join(_HERE, "lib", "libnbody_hip.so")
 
 # status codes (include/nbody_hip.h: nbody_hip_status)
 OK, ERR_VALIDATION, ERR_DEVICE, ERR_RESOURCE, ERR_STATE, ERR_COMM = 0, -1, -2, -3, -4, -5

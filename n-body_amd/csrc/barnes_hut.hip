@@ -60,6 +60,10 @@ namespace nbh {
 #ifndef NBH_BH_XCD
 #define NBH_BH_XCD 1
 #endif
+// pair walk: the fp32 sums of this many sibling groups (1 or 2) are folded into the fp64 totals at a time
+#ifndef NBH_BH_FOLD
+#define NBH_BH_FOLD 1
+#endif
 
 constexpr int kMaxDepth = 21;      // 63-bit Morton keys (the reference caps its insertion at depth 20, :363)
 constexpr int kDepth32 = 10;       // up to here 30-bit keys in 32-bit words (the faster sort)
@@ -921,6 +925,8 @@ struct PairArgs {
   float G;
 };
 
+typedef int i3v __attribute__((ext_vector_type(3)));  // 16-byte aligned: ds_read_b96 / ds_write_b96 of a stack entry
+
 template <bool GUARD, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void bh_traverse_pair_kernel(PairArgs a) {
 #pragma clang fp contract(off)  // distances and the opening test round exactly like the oracle
@@ -942,8 +948,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
   double sx = 0.0, sy = 0.0, sz = 0.0;
   const unsigned long long m0 = __ballot(valid);
   if (m0 == 0ull) return;  // wave-uniform
-  // entry = (first child, children | "a child is a leaf of several bodies" << 8, 64-bit lane mask)
-  if (lane == 0) stk[w][0] = make_int4(0, 1, (int)(unsigned)(m0 & 0xffffffffull), (int)(unsigned)(m0 >> 32));
+  // entry = (link word of the group's parent as the records hold it: first child | (children - 1) << 28 | "a child
+  // is a leaf of several bodies" << 31, 64-bit lane mask): three words, pushed as the parent's link VERBATIM
+  // (round 2: four words, unpacked at the push: one register move and two scalar operations more per push / pop)
+  if (lane == 0) stk[w][0] = make_int4(0, (int)(unsigned)(m0 & 0xffffffffull), (int)(unsigned)(m0 >> 32), 0);
   int sp = 1;
   __builtin_amdgcn_wave_barrier();
   // eps^2 and theta^2 as packed VGPR constants (SGPRs are the scarce resource of this kernel)
@@ -952,13 +960,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
   asm("v_mov_b32 %0, %1" : "=v"(th2s) : "s"(theta2));
   const f2 e2 = f2{e2s, e2s}, th2 = f2{th2s, th2s};
   unsigned long long visited = 0;
+  f2 ax = f2{0.f, 0.f}, ay = ax, az = ax;
+#if NBH_BH_FOLD != 1
+  int groups = 0;
+#endif
 
   while (sp > 0) {
     sp--;
-    const int4 e = stk[w][sp];
-    const unsigned int c0 = (unsigned int)rfl(e.x);
-    const int cnf = rfl(e.y), cn = cnf & 0xff;
-    const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.w) << 32) | (unsigned)rfl(e.z);
+    const i3v e = *reinterpret_cast<const i3v*>(&stk[w][sp]);
+    const unsigned int link = (unsigned int)rfl(e.x);
+    const unsigned int c0 = link & 0x0fffffffu;
+    const int cn = (int)((link >> 28) & 7u) + 1;
+    const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.z) << 32) | (unsigned)rfl(e.y);
     visited += cn;
     // the group's pair blocks (ids c0 .. c0 + cn - 1 -> blocks c0 / 2 .. (c0 + cn - 1) / 2, at most five, one
     // contiguous run): three always, the last two only for groups that reach them
@@ -983,7 +996,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     // the first block's even node / the last block's odd node may belong to another group
     const unsigned long long Mfirst = (c0 & 1u) ? 0ull : M;
     const unsigned long long Mlast = ((c0 + (unsigned int)cn) & 1u) ? 0ull : M;
-    f2 ax = f2{0.f, 0.f}, ay = ax, az = ax;
+#if NBH_BH_FOLD == 1
+    ax = f2{0.f, 0.f}; ay = ax; az = ax;
+#endif
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       if (k >= nb) break;  // wave-uniform
@@ -1026,18 +1041,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
       const unsigned long long Oa = Ma & ~Fa, Ob = Mb & ~Fb;
       if (Oa != 0ull) {
         // (every lane stores the same entry to the same address: no lane predicate to keep in SGPRs)
-          stk[w][sp] = make_int4((int)(q[10] & 0x0fffffffu), (int)(((q[10] >> 28) & 7u) + 1u + ((q[10] >> 31) << 8)),
-                                 (int)(unsigned)(Oa & 0xffffffffull), (int)(unsigned)(Oa >> 32));
+        *reinterpret_cast<i3v*>(&stk[w][sp]) = i3v{(int)q[10], (int)(unsigned)(Oa & 0xffffffffull), (int)(unsigned)(Oa >> 32)};
         sp++;
       }
       if (Ob != 0ull) {
-        // (every lane stores the same entry to the same address: no lane predicate to keep in SGPRs)
-          stk[w][sp] = make_int4((int)(q[11] & 0x0fffffffu), (int)(((q[11] >> 28) & 7u) + 1u + ((q[11] >> 31) << 8)),
-                                 (int)(unsigned)(Ob & 0xffffffffull), (int)(unsigned)(Ob >> 32));
+        *reinterpret_cast<i3v*>(&stk[w][sp]) = i3v{(int)q[11], (int)(unsigned)(Ob & 0xffffffffull), (int)(unsigned)(Ob >> 32)};
         sp++;
       }
     }
-    if (cnf & 256) {  // leaves of several bodies (depth limit, leaf_max > 1): body by body, exact
+    if (link & kManyBit) {  // leaves of several bodies (depth limit, leaf_max > 1): body by body, exact
       const bool in = __builtin_amdgcn_inverse_ballot_w64(M);
       for (int k = 0; k < cn; k++) {
         const NodeRec nd = a.rec[c0 + k];
@@ -1054,9 +1066,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
         }
       }
     }
+#if NBH_BH_FOLD == 1
     sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
+#else
+    if ((++groups & (NBH_BH_FOLD - 1)) == 0) {  // fp32 sums of NBH_BH_FOLD sibling groups folded into fp64
+      sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
+      ax = f2{0.f, 0.f}; ay = ax; az = ax;
+    }
+#endif
     __builtin_amdgcn_wave_barrier();
   }
+#if NBH_BH_FOLD != 1
+  sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
+#endif
   // epilogue arguments, fetched now (see PairArgs)
   const PairArgs* ka = (const PairArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm("" : "+s"(ka));

@@ -254,3 +254,19 @@ def test_direct_oracle_equals_reference_cpu_loop(oracle, name):
         gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plummer4096_direct.npz"))
         assert np.array_equal(gold["acc_f32seq"], ref)
         assert np.array_equal(gold["pos_x"], x) and np.array_equal(gold["mass"], m)
+
+
+# The cutoff / opening distance of the oracle is the chain nvcc's default contraction is ASSUMED to make of the
+# reference's `dx*dx + dy*dy + dz*dz` (one product, two fused multiply-adds) -- no reference
+# fixture covers that choice.  Cross-check at tolerance level: the vectors of the round-1 oracle, which formed the
+# distance UNcontracted, are kept (tests/golden/uniform4096_spatial_hash_uncontracted_cutoff.npz); the two must agree
+# to fp32 rounding of a term (no pair of this fixture sits within an ulp of the cutoff sphere).
+def test_spatial_hash_fixture_vs_uncontracted_cutoff_distance():
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    new, old = np.load(os.path.join(here, "uniform4096_spatial_hash.npz")), \
+        np.load(os.path.join(here, "uniform4096_spatial_hash_uncontracted_cutoff.npz"))
+    for k in ("acc_c1", "acc_c2"):
+        a, b = new[k].astype(np.float64), old[k].astype(np.float64)
+        e = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-300)
+        assert e.max() < 5e-6, (k, e.max())

@@ -17,7 +17,7 @@ for line in out.splitlines():
         cur = {"name": subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()}
         rows.append(cur)
         continue
-    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/\w+\])?: (\d+)", line)
+    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[\w/]+\])?: (\d+)", line)
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
     if "error" in line:
@@ -26,5 +26,5 @@ for r in rows:
     if flt and flt not in r["name"]:
         continue
     name = re.sub(r"\(.*", "", r["name"]).replace("nbh::", "").replace("void ", "")
-    print(f"{name:60s} vgpr {r.get('VGPRs', 0):3d} agpr {r.get('AGPRs', 0):3d} sgpr {r.get('SGPRs', 0):3d} "
+    print(f"{name:60s} vgpr {r.get('VGPRs', 0):3d} agpr {r.get('AGPRs', 0):3d} sgpr {r.get('TotalSGPRs', 0):3d} "
           f"scratch {r.get('ScratchSize', 0):4d} lds {r.get('LDS Size', 0):6d} occ {r.get('Occupancy', 0)}")
