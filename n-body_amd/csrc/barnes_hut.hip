@@ -1259,6 +1259,14 @@ struct nbody_hip_tree {
   bool tune_schedule = true;
   bool count_visits = false;
   size_t built_count = 0;
+  // A side stream for the small passes that do not depend on the build's critical path: the double-double prefix sums
+  // of the sorted bodies (needed only by the monopole pass) run beside the level ranks + fill pass, and the walk's
+  // cost-ordered schedule (a function of the PREVIOUS walk's visit counts) beside the whole build.  Fork / join by
+  // events on the context's stream; not used while a step graph is being recorded.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_plan = nullptr;
+  bool plan_pending = false;     // the schedule for the full range was queued on the side stream by the last build
+  int plan_n = -1, plan_cap = 0;
 };
 
 static void tree_release(nbody_hip_tree* g) {
@@ -1268,6 +1276,9 @@ static void tree_release(nbody_hip_tree* g) {
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
   for (void* p : ptrs) (void)hipFree(p);
+  for (hipEvent_t e : {g->ev_fork, g->ev_join, g->ev_plan})
+    if (e) (void)hipEventDestroy(e);
+  if (g->side) (void)hipStreamDestroy(g->side);
   delete g;
 }
 
@@ -1349,6 +1360,9 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
   if (e == hipSuccess) e = dmalloc(&g->d_totals, kMaxDepth + 3);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
+  for (hipEvent_t* ev : {&g->ev_fork, &g->ev_join, &g->ev_plan})
+    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_a, n);
   if (e == hipSuccess) e = dmalloc(&g->d_idx_b, n);
   if (e == hipSuccess) e = dmalloc(&g->d_sorted, n);
@@ -1378,6 +1392,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
 extern "C" int nbody_hip_tree_destroy(nbody_hip_tree* g) {
   if (!g) return NBODY_HIP_OK;
   (void)hipSetDevice(g->ctx->device);
+  if (g->side) (void)hipStreamSynchronize(g->side);
   (void)hipStreamSynchronize(g->ctx->stream);
   g->ctx->alloc_generation++;  // a step graph recorded with this tree is stale now
   tree_release(g);
@@ -1396,6 +1411,7 @@ extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int l
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_depth %d with leaf_max %d needs more than 2^28 nodes for %zu bodies",
                     max_depth, leaf_max, g->max_particles);
   NBH_HIP(hipSetDevice(g->ctx->device));
+  if (g->side) NBH_HIP(hipStreamSynchronize(g->side));
   NBH_HIP(hipStreamSynchronize(g->ctx->stream));
   g->max_depth = max_depth;
   g->leaf_max = leaf_max;
@@ -1410,6 +1426,7 @@ extern "C" int nbody_hip_tree_limit_nodes(nbody_hip_tree* g, int max_nodes) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null tree");
   if (max_nodes < 0 || (max_nodes > 0 && max_nodes < 16)) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "max_nodes must be 0 or >= 16");
   NBH_HIP(hipSetDevice(g->ctx->device));
+  if (g->side) NBH_HIP(hipStreamSynchronize(g->side));
   NBH_HIP(hipStreamSynchronize(g->ctx->stream));
   g->node_limit = max_nodes;
   g->built_count = 0;
@@ -1442,9 +1459,29 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   } else {
     if (int rc = launch_bbox(ctx, posm, ni, enc, !armed)) return rc;
   }
-  // topology of every level: keys, sort, flags, one scan, fill (see tree_flags_kernel)
+  const bool side_ok = g->side != nullptr && !ctx->capturing;
+  // the walk's cost-ordered schedule depends only on the visit counts the previous walk of the full range recorded:
+  // queue it on the side stream now, beside the build (28 us off the step's critical path)
+  g->plan_pending = false;
+  {
+    const int waves = (ni + 63) / 64;
+    if (side_ok && g->tune_schedule && g->cost_first == 0 && g->cost_n == ni && waves >= 2048) {
+      const int cap = waves / 8 + waves / 32 + 8;
+      NBH_HIP(hipEventRecord(g->ev_fork, st));
+      NBH_HIP(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+      hipLaunchKernelGGL(walk_plan_kernel, dim3(1), dim3(kPlanBlock), 0, g->side, g->d_cost, waves, cap, g->d_bounds);
+      hipLaunchKernelGGL(walk_order_kernel, dim3(8), dim3(kPlanBlock), 0, g->side, g->d_cost, g->d_bounds, cap, g->d_order);
+      NBH_LAUNCH_CHECK();
+      NBH_HIP(hipEventRecord(g->ev_plan, g->side));
+      g->plan_pending = true;
+      g->plan_n = ni;
+      g->plan_cap = cap;
+    }
+  }
+  // topology of every level: keys, sort, flags, ranks, fill (see tree_flags_kernel)
   const int levels = g->max_depth + 1;
   const bool fused = ni <= kPrefixMax;
+  bool prefix_forked = false;
   auto topology = [&](auto* ka, auto* kb, int first_bit, int key_bits) -> int {
     using K = std::remove_pointer_t<decltype(ka)>;
     hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, enc, enc_next, g->d_root,
@@ -1460,6 +1497,18 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     const int G = (ni + 63) / 64;
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
                        lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, G);
+    if (fused && side_ok) {
+      // the prefix sums of the sorted bodies only feed the monopole pass: beside the ranks + fill pass
+      const int pblocks = ni / kPrefixBlock + 1;
+      dd4* btot = g->d_prefix + g->prefix_cap;
+      dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
+      NBH_HIP(hipEventRecord(g->ev_fork, st));
+      NBH_HIP(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+      hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, g->side, g->d_sorted, ni, g->d_prefix, btot);
+      hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, g->side, pblocks, btot, boff);
+      NBH_HIP(hipEventRecord(g->ev_join, g->side));
+      prefix_forked = true;
+    }
     hipLaunchKernelGGL(level_scan_kernel, dim3(levels), dim3(kScanBlock), 0, st, g->d_rank_off, G, g->d_totals);
     NBH_LAUNCH_CHECK();
     const LevelRanks lr{g->d_plane, g->d_rank_off, G};
@@ -1484,8 +1533,12 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     const int pblocks = ni / kPrefixBlock + 1;
     dd4* btot = g->d_prefix + g->prefix_cap;
     dd4* boff = btot + kPrefixMax / kPrefixBlock + 2;
-    hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix, btot);
-    hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
+    if (prefix_forked) {
+      NBH_HIP(hipStreamWaitEvent(st, g->ev_join, 0));
+    } else {
+      hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix, btot);
+      hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
+    }
     // the node count is only known on the device: one thread per possible node of a tree of ni bodies
     const size_t node_bound = std::min((size_t)g->capacity,
                                        n + (size_t)levels * (n / (size_t)(g->leaf_max + 1) + 1) + 16);
@@ -1563,6 +1616,8 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   const float eps2 = eps * eps, theta2 = theta * theta;  // :494-496
   unsigned long long* visits = g->count_visits ? g->d_visits : nullptr;
   if (visits) NBH_HIP(hipMemsetAsync(visits, 0, kVisitWords * sizeof(unsigned long long), ctx->stream));
+  // a schedule queued beside the build reads the cost array this walk is about to rewrite: order after it in any case
+  if (g->plan_pending && !ctx->capturing) NBH_HIP(hipStreamWaitEvent(ctx->stream, g->ev_plan, 0));
   if (n == 0) return NBODY_HIP_OK;
   // replicas of the walk when there are too few waves to hide the fetch latency (see the kernel)
   int K = 1;
@@ -1600,13 +1655,18 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
     if (g->tune_schedule && g->cost_first == first && g->cost_n == n && waves >= 2048) {
       // the previous walk of this range recorded every wave's node visits: longest first, equal cost per XCD
       const int cap = waves / 8 + waves / 32 + 8;
-      hipLaunchKernelGGL(walk_plan_kernel, dim3(1), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, waves, cap,
-                         g->d_bounds);
-      hipLaunchKernelGGL(walk_order_kernel, dim3(8), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, g->d_bounds, cap,
-                         g->d_order);
+      if (g->plan_pending && first == 0 && g->plan_n == n && g->plan_cap == cap && !ctx->capturing) {
+        // queued beside the build (tree_build_packed); the stream already waits for it (above)
+      } else {
+        hipLaunchKernelGGL(walk_plan_kernel, dim3(1), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, waves, cap,
+                           g->d_bounds);
+        hipLaunchKernelGGL(walk_order_kernel, dim3(8), dim3(kPlanBlock), 0, ctx->stream, g->d_cost, g->d_bounds, cap,
+                           g->d_order);
+      }
       order = g->d_order;
       grid = 8 * cap;
     }
+    g->plan_pending = false;  // a second walk of the same build recorded new costs: it plans for itself
     PairArgs pa;
     pa.pb = g->t.pb; pa.rec = g->t.rec; pa.sorted = g->d_sorted; pa.order = order;
     pa.t_first = first; pa.n = n; pa.theta2 = theta2; pa.eps2 = eps2;
