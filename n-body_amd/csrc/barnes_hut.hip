@@ -220,19 +220,6 @@ __device__ __forceinline__ void store_node(const TreeArrays& t, int nid, int lev
   q[10] = link;
 }
 
-// the same for a caller that already knows whether a child is a leaf of several bodies (fused fill pass)
-__device__ __forceinline__ void store_node_fused(const TreeArrays& t, int nid, const NodeRec& r, bool many) {
-  t.rec[nid] = r;
-  const bool leaf = r.child == 0u;
-  unsigned int link = leaf ? (r.count == 1 ? 0u : kManyLeaf) : ((r.child & 0x0fffffffu) | (((r.child >> 28) - 1u) << 28));
-  if (!leaf && many) link |= kManyBit;
-  unsigned int* q = t.pb + (size_t)(nid >> 1) * kPairWords + (nid & 1);
-  q[0] = __float_as_uint(r.cx); q[2] = __float_as_uint(r.cy); q[4] = __float_as_uint(r.cz);
-  q[6] = __float_as_uint((leaf && r.count != 1) ? 0.f : r.mass);
-  q[8] = __float_as_uint(leaf ? -1.0f : r.size2);
-  q[10] = link;
-}
-
 // ---------------------------------------------------------------------------------------
 // Topology from the sorted keys alone, all levels at once.
 //
@@ -261,7 +248,16 @@ __device__ __forceinline__ int side_extent(const K* __restrict__ keys, int i, in
 // plane[L][g] = ballot of the level-L flag over the 64 bodies of group g (= one wave of tree_flags_kernel), and
 // off[L][g] = number of level-L flags before group g (one small workgroup per level scans the popcounts).  The
 // inclusive rank of body j at level L -- how many level-L nodes start at or before j -- is then two loads and a
-// popcount, wherever j lies; node id = (nodes of the levels above) + rank - 1.  4.3 MB of tables at N = 2^20.
+// popcount, wherever j lies.  4.3 MB of tables at N = 2^20.
+//
+// EVEN-ALIGNED SIBLING GROUPS.  The pair walk evaluates two nodes per packed instruction out of 48-byte blocks that
+// hold nodes 2i and 2i + 1, so a sibling group should start on an even id: a group of two that starts odd costs two
+// pair steps instead of one (unweighted over the two-galaxy tree of config 4: 2.00 pair steps per group against 1.66
+// aligned).  Every group is therefore padded to an even number of ids: id = B[L] + (level-L nodes at or before the
+// body) - 1 + (ODD-sized level-L groups that END at or before the body), B[L] = first id of level L (even).  The second
+// count is a rank in a second set of planes: a group of odd size sets a marker at the position one past its last body
+// (= its parent's `last`): every earlier group's marker lies at or before the start of a later group, a group's own
+// marker lies behind all its bodies.  An odd group's last slot + 1 is a HOLE: an id without a node (first = -1).
 struct LevelRanks {
   const unsigned long long* plane;  // [levels][G]
   const int* off;                   // [levels][G]: exclusive prefix of the popcounts of a level
@@ -291,8 +287,7 @@ __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict_
                                                             const float4* __restrict__ posm,
                                                             const int* __restrict__ sorted_idx,
                                                             float4* __restrict__ sorted,
-                                                            unsigned long long* __restrict__ plane,
-                                                            int* __restrict__ cnt, int G) {
+                                                            unsigned long long* __restrict__ plane, int G) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   unsigned int mask = 0;
   if (i < n) {
@@ -324,25 +319,27 @@ __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict_
     const unsigned long long b = __ballot((mask >> L) & 1u);
     if (lane == L) mine = b;
   }
-  if (lane <= max_depth && g < G) {
-    plane[(size_t)lane * G + g] = mine;
-    cnt[(size_t)lane * G + g] = __popcll(mine);
-  }
+  if (lane <= max_depth && g < G) plane[(size_t)lane * G + g] = mine;
 }
 
-// one workgroup per level: off[L][g] <- number of level-L flags before group g (in place over the popcounts),
-// totals[L] <- nodes of the level
+// one workgroup per (table, level): off[L][g] <- number of flags of plane[L] before group g, totals[L] <- flags of the
+// level.  blockIdx.y selects the table (0: node flags, 1: odd-group markers)
 constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(kScanBlock) void level_scan_kernel(int* __restrict__ off, int G, int* __restrict__ totals) {
+__global__ __launch_bounds__(kScanBlock) void level_scan_kernel(const unsigned long long* __restrict__ plane0,
+                                                                int* __restrict__ off0, int* __restrict__ totals0,
+                                                                const unsigned long long* __restrict__ plane1,
+                                                                int* __restrict__ off1, int* __restrict__ totals1, int G) {
   constexpr int NW = kScanBlock / 64;
   __shared__ int wsum[NW];
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int* o = off + (size_t)L * G;
+  const unsigned long long* pl = (blockIdx.y ? plane1 : plane0) + (size_t)L * G;
+  int* o = (blockIdx.y ? off1 : off0) + (size_t)L * G;
+  int* totals = blockIdx.y ? totals1 : totals0;
   // wave wv owns the contiguous chunk [c0, c1) (a multiple of 64 long): coalesced loads, shuffle scans
   const int per = ((G + NW - 1) / NW + 63) & ~63;
   const int c0 = min(G, wv * per), c1 = min(G, c0 + per);
   int sum = 0;
-  for (int g = c0 + lane; g < c1; g += 64) sum += o[g];
+  for (int g = c0 + lane; g < c1; g += 64) sum += __popcll(pl[g]);
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
   if (lane == 0) wsum[wv] = sum;
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(kScanBlock) void level_scan_kernel(int* __restrict_
     total += wsum[k];
   }
   for (int g = c0; g < c1; g += 64) {
-    const int c = g + lane < c1 ? o[g + lane] : 0;
+    const int c = g + lane < c1 ? __popcll(pl[g + lane]) : 0;
     int inc = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -366,49 +363,31 @@ __global__ __launch_bounds__(kScanBlock) void level_scan_kernel(int* __restrict_
   if (tid == 0) totals[L] = total;
 }
 
-// One thread per BODY: it fills the nodes this body heads (the set bits of its level mask; 1.3 nodes per
-// body on average), instead of one thread per (level, body) entry of the flag array, 21 of 22 of which
-// would only find a zero flag (145 -> 60 us at N = 2^20, 21 levels).
-// FUSED (trees of <= kPrefixMax bodies): the node's monopole comes from the double-double prefix sums over the sorted
-// bodies right here -- no second pass over the nodes (prefix_monopole_kernel of round 2: 49 us and a re-read of the
-// four range / link arrays).
-struct dd4;
-struct PrefixSums {
-  const dd4* P;     // entry k = sums over the workgroup's bodies before k
-  const dd4* boff;  // workgroup offsets
-};
-__device__ __forceinline__ double4 prefix_monopole(const PrefixSums& ps, const float4* __restrict__ sorted, int first, int last);
-__device__ __forceinline__ void store_node_fused(const TreeArrays& t, int nid, const NodeRec& r, bool many);
-
-template <class K, bool FUSED>
-__global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__ keys,
-                                                           int n, int max_depth, int leaf_max,
-                                                           const unsigned int* __restrict__ lvlmask,
-                                                           LevelRanks lr, const int* __restrict__ totals,
-                                                           TreeArrays t, int capacity,
-                                                           int* __restrict__ level_base,
-                                                           const float4* __restrict__ sorted, PrefixSums ps,
-                                                           const TreeRoot* __restrict__ root) {
-  // ids of level L start where the levels above end: ubase (unclamped; an id >= capacity does not exist)
+// Body ranges and group parities, one thread per BODY over the levels it heads (like the fill pass): the end of
+// every node's body range (a gallop + binary search in the sorted keys) is stored under the node's PROVISIONAL id
+// (plain rank, no padding) for the fill pass, and every internal node whose child count is odd sets its marker in
+// the odd-group planes of the level below.
+template <class K>
+__global__ __launch_bounds__(kBlock) void tree_span_kernel(const K* __restrict__ keys, int n, int max_depth, int leaf_max,
+                                                           const unsigned int* __restrict__ lvlmask, LevelRanks lr,
+                                                           const int* __restrict__ totals, int capacity,
+                                                           int* __restrict__ last_tmp,
+                                                           unsigned long long* __restrict__ odd_plane) {
   __shared__ int ubase[kMaxDepth + 3];
   if (threadIdx.x == 0) {
     int run = 0;
     for (int L = 0; L <= max_depth; L++) { ubase[L] = run; run += totals[L]; }
-    ubase[max_depth + 1] = run;
   }
   __syncthreads();
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i <= max_depth + 1) level_base[i] = min(ubase[i], capacity);  // thread L of the first block (256 > levels)
-  if (i == 0) level_base[kMaxDepth + 2] = ubase[max_depth + 1];     // the UNCLAMPED node total (TreeArrays::node_total)
   if (i >= n) return;
-  const bool overflow = ubase[max_depth + 1] > capacity;
   unsigned int m = lvlmask[i];
   const K key = keys[i];
   while (m) {
     const int L = __ffs(m) - 1;
     m &= m - 1;
-    const int nid = ubase[L] + lr.rank(L, i) - 1;
-    if (nid >= capacity) continue;  // beyond the node arrays: this node does not exist (its parent is a leaf)
+    const int pid = ubase[L] + lr.rank(L, i) - 1;
+    if (pid >= capacity) continue;
     const int shift = KeyTraits<K>::kTop - 3 * L;
     // one past the last body of the group: first j > i with another prefix
     int last = n;
@@ -425,50 +404,90 @@ __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__
       }
       last = lo;
     }
+    last_tmp[pid] = last;
+    if (L < max_depth && last - i > leaf_max) {
+      const int cn = lr.rank(L + 1, last - 1) - lr.rank(L + 1, i) + 1;
+      if (cn & 1) atomicOr(&odd_plane[(size_t)(L + 1) * lr.G + (size_t)(last >> 6)], 1ull << (last & 63));
+    }
+  }
+}
+
+// One thread per BODY: it fills the nodes this body heads (the set bits of its level mask; 1.3 nodes per
+// body on average), instead of one thread per (level, body) entry of the flag array, 21 of 22 of which
+// would only find a zero flag (145 -> 60 us at N = 2^20, 21 levels).  Ids are the even-aligned ones (see LevelRanks).
+struct dd4;
+struct PrefixSums {
+  const dd4* P;     // entry k = sums over the workgroup's bodies before k
+  const dd4* boff;  // workgroup offsets
+};
+__device__ __forceinline__ double4 prefix_monopole(const PrefixSums& ps, const float4* __restrict__ sorted, int first, int last);
+
+// a hole's half of its pair block must be inert whatever an earlier build left there (the walk masks its lanes out, but
+// 0 x NaN is NaN): at the origin, massless, marked as a leaf (never opened)
+__device__ __forceinline__ void mark_hole(const TreeArrays& t, int hole) {
+  t.first[hole] = -1;
+  unsigned int* q = t.pb + (size_t)(hole >> 1) * kPairWords + (hole & 1);
+  q[0] = 0u; q[2] = 0u; q[4] = 0u; q[6] = 0u;
+  q[8] = __float_as_uint(-1.0f);
+  q[10] = 0u;
+}
+
+template <class K>
+__global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__ keys,
+                                                           int n, int max_depth, int leaf_max,
+                                                           const unsigned int* __restrict__ lvlmask,
+                                                           LevelRanks lr, LevelRanks odd, const int* __restrict__ totals,
+                                                           const int* __restrict__ odd_totals,
+                                                           const int* __restrict__ last_tmp,
+                                                           TreeArrays t, int capacity,
+                                                           int* __restrict__ level_base, int* __restrict__ level_real) {
+  // ubase: provisional (unpadded) first id of a level = real nodes above it; base: first id of a level (even)
+  __shared__ int ubase[kMaxDepth + 3], base[kMaxDepth + 3];
+  if (threadIdx.x == 0) {
+    int run = 0, idrun = 0;
+    for (int L = 0; L <= max_depth; L++) {
+      ubase[L] = run;
+      base[L] = idrun;
+      run += totals[L];
+      idrun += L == 0 ? 2 : totals[L] + odd_totals[L];  // the root's slot 1 is a hole; every other level is even
+    }
+    ubase[max_depth + 1] = run;
+    base[max_depth + 1] = idrun;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i <= max_depth + 1) {  // thread L of the first block (256 > levels)
+    level_base[i] = min(base[i], capacity);
+    level_real[i] = ubase[i];
+  }
+  if (i == 0) {
+    level_base[kMaxDepth + 2] = base[max_depth + 1];  // the UNCLAMPED id total (TreeArrays::node_total)
+    if (1 < capacity) mark_hole(t, 1);                 // the hole beside the root
+  }
+  if (i >= n) return;
+  unsigned int m = lvlmask[i];
+  while (m) {
+    const int L = __ffs(m) - 1;
+    m &= m - 1;
+    const int rk = lr.rank(L, i);
+    const int pid = ubase[L] + rk - 1;
+    const int nid = base[L] + rk - 1 + (L > 0 ? odd.rank(L, i) : 0);
+    if (nid >= capacity || pid >= capacity) continue;  // beyond the node arrays: this node does not exist (its parent is a leaf)
+    const int last = last_tmp[pid];
     t.first[nid] = i;
     t.last[nid] = last;
     int c0 = -1, c1 = -1;
     if (L < max_depth && last - i > leaf_max) {
       // children: the flagged bodies of level L + 1 inside [i, last); body i is always one of them
-      c0 = ubase[L + 1] + lr.rank(L + 1, i) - 1;
-      c1 = ubase[L + 1] + lr.rank(L + 1, last - 1) - 1;
-      if (c1 >= capacity) { c0 = -1; c1 = -1; }
+      const int r0 = lr.rank(L + 1, i);
+      const int cn = lr.rank(L + 1, last - 1) - r0 + 1;
+      c0 = base[L + 1] + r0 - 1 + odd.rank(L + 1, i);
+      c1 = c0 + cn - 1;
+      if (c1 >= capacity || ubase[L + 1] + r0 - 1 + cn - 1 >= capacity) { c0 = -1; c1 = -1; }
+      else if ((cn & 1) && c1 + 1 < capacity) mark_hole(t, c1 + 1);  // the hole that pads an odd group
     }
     t.child0[nid] = c0;
     t.child_last[nid] = c1;
-    if constexpr (FUSED) {
-      const int cnt = last - i;
-      const double4 mono = prefix_monopole(ps, sorted, i, last);
-      const float h = ldexpf(root->half, -L);
-      const float size = 2.0f * h;  // :168
-      NodeRec r;
-      r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
-      r.size2 = size * size;
-      r.first = i; r.count = cnt;
-      r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(c1 - c0 + 1) << 28));
-      // is one of the children a leaf of several bodies?  Only where a node may not be split: at the depth limit,
-      // with leaf_max > 1, or when the node arrays overflowed.  Asked of the bit planes (the children's own records
-      // are being written by other threads of this very launch).
-      bool many = false;
-      if (c0 >= 0 && (L + 1 >= t.scan_from || overflow)) {
-        const int nchild = c1 - c0 + 1;
-        if (L + 1 == max_depth) {
-          many = cnt > nchild;  // every child is a leaf: some child holds two or more bodies
-        } else {
-          const int r0 = lr.rank(L + 1, i);
-          int h0 = i;
-          for (int k = 0; k < nchild && !many; k++) {
-            const int h1 = k + 1 < nchild ? lr.select(L + 1, r0 + k + 1) : last;
-            const int cc = h1 - h0;
-            bool leaf = cc <= leaf_max;
-            if (!leaf) leaf = ubase[L + 2] + lr.rank(L + 2, h1 - 1) - 1 >= capacity;  // its children do not exist
-            many = leaf && cc != 1;
-            h0 = h1;
-          }
-        }
-      }
-      store_node_fused(t, nid, r, many);
-    }
   }
 }
 
@@ -479,6 +498,7 @@ __device__ __forceinline__ void monopole_level(int level, const int* __restrict_
                                                const TreeRoot* __restrict__ root, TreeArrays t) {
   const int lo = level_base[level], hi = level_base[level + 1];
   for (int nid = lo + blockIdx.x * BLOCK + threadIdx.x; nid < hi; nid += gridDim.x * BLOCK) {
+    if (t.first[nid] < 0) continue;  // a hole (padding of an odd sibling group)
     const int first = t.first[nid], cnt = t.last[nid] - first;
     const int c0 = t.child0[nid];
     double mx = 0.0, my = 0.0, mz = 0.0, ms = 0.0;
@@ -695,21 +715,24 @@ __device__ __forceinline__ double4 prefix_monopole(const PrefixSums& ps, const f
 __global__ __launch_bounds__(kBlock) void prefix_monopole_kernel(const int* __restrict__ level_base, int max_depth,
                                                                  const float4* __restrict__ sorted, PrefixSums ps,
                                                                  const TreeRoot* __restrict__ root, TreeArrays t) {
-  const int nid = blockIdx.x * kBlock + threadIdx.x;
-  if (nid >= level_base[max_depth + 1]) return;
-  int level = 0;
-  while (level < max_depth && nid >= level_base[level + 1]) level++;
-  const int first = t.first[nid], last = t.last[nid], cnt = last - first;
-  const int c0 = t.child0[nid];
-  const double4 mono = prefix_monopole(ps, sorted, first, last);
-  const float h = ldexpf(root->half, -level);
-  const float size = 2.0f * h;  // :168
-  NodeRec r;
-  r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
-  r.size2 = size * size;
-  r.first = first; r.count = cnt;
-  r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
-  store_node(t, nid, level, r);
+  // the id count is only known on the device: a fixed grid strides over it
+  const int total = level_base[max_depth + 1];
+  for (int nid = blockIdx.x * kBlock + threadIdx.x; nid < total; nid += gridDim.x * kBlock) {
+    int level = 0;
+    while (level < max_depth && nid >= level_base[level + 1]) level++;
+    const int first = t.first[nid], last = t.last[nid], cnt = last - first;
+    if (first < 0) continue;  // a hole (padding of an odd sibling group)
+    const int c0 = t.child0[nid];
+    const double4 mono = prefix_monopole(ps, sorted, first, last);
+    const float h = ldexpf(root->half, -level);
+    const float size = 2.0f * h;  // :168
+    NodeRec r;
+    r.cx = (float)mono.x; r.cy = (float)mono.y; r.cz = (float)mono.z; r.mass = (float)mono.w;
+    r.size2 = size * size;
+    r.first = first; r.count = cnt;
+    r.child = c0 < 0 ? 0u : ((unsigned)c0 | ((unsigned)(t.child_last[nid] - c0 + 1) << 28));
+    store_node(t, nid, level, r);
+  }
 }
 
 constexpr int kVisitWords = 131;  // [0] node visits; [1..65] by lanes testing; [66..130] by lanes accepting
@@ -973,10 +996,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     const int cn = (int)((link >> 28) & 7u) + 1;
     const unsigned long long M = ((unsigned long long)(unsigned)rfl(e.z) << 32) | (unsigned)rfl(e.y);
     visited += cn;
-    // the group's pair blocks (ids c0 .. c0 + cn - 1 -> blocks c0 / 2 .. (c0 + cn - 1) / 2, at most five, one
-    // contiguous run): three always, the last two only for groups that reach them
+    // the group's pair blocks: sibling groups start on an EVEN id (see LevelRanks), so ids c0 .. c0 + cn - 1 are
+    // blocks c0 / 2 .. c0 / 2 + ceil(cn / 2) - 1, at most four, one contiguous run: three always, the fourth only
+    // for groups of seven or eight
     const unsigned int fb = c0 >> 1;
-    const int nb = (int)(((c0 + (unsigned int)cn - 1u) >> 1) - fb) + 1;
+    const int nb = (cn + 1) >> 1;
     const unsigned int* gp = a.pb + (size_t)fb * kPairWords;
     // three blocks up front; a group that reaches blocks 3 and 4 (six or more children) fetches them into the
     // same registers once the first three are done: 36 instead of 60 SGPRs of node data keep the kernel at
@@ -993,26 +1017,25 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
 #pragma unroll
       for (int k = 0; k < 4; k++) blk[32 + k] = v2[k];
     }
-    // the first block's even node / the last block's odd node may belong to another group
-    const unsigned long long Mfirst = (c0 & 1u) ? 0ull : M;
-    const unsigned long long Mlast = ((c0 + (unsigned int)cn) & 1u) ? 0ull : M;
+    // the last block's odd node is the padding of an odd group
+    const unsigned long long Mlast = (cn & 1) ? 0ull : M;
 #if NBH_BH_FOLD == 1
     ax = f2{0.f, 0.f}; ay = ax; az = ax;
 #endif
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 4; k++) {
       if (k >= nb) break;  // wave-uniform
       if (k == 3) {
-        u16v v3 = *reinterpret_cast<const u16v*>(gp + 36);
-        u8v v4 = *reinterpret_cast<const u8v*>(gp + 52);
+        u8v v3 = *reinterpret_cast<const u8v*>(gp + 36);
+        u4v v4 = *reinterpret_cast<const u4v*>(gp + 44);
         asm("" : "+s"(v3), "+s"(v4));
 #pragma unroll
-        for (int i = 0; i < 16; i++) blk[i] = v3[i];
+        for (int i = 0; i < 8; i++) blk[i] = v3[i];
 #pragma unroll
-        for (int i = 0; i < 8; i++) blk[16 + i] = v4[i];
+        for (int i = 0; i < 4; i++) blk[8 + i] = v4[i];
       }
       const unsigned int* q = blk + (k % 3) * kPairWords;
-      const unsigned long long Ma = k == 0 ? Mfirst : M;
+      const unsigned long long Ma = M;
       const unsigned long long Mb = k == nb - 1 ? Mlast : M;
       const f2 dx = f2{__uint_as_float(q[0]), __uint_as_float(q[1])} - px,
                dy = f2{__uint_as_float(q[2]), __uint_as_float(q[3])} - py,
@@ -1237,9 +1260,11 @@ struct nbody_hip_tree {
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
   // node numbering (LevelRanks): bit planes and per-group offsets of every level, the level totals
-  unsigned long long* d_plane = nullptr;  // (max_depth + 1) * rank_G
-  int* d_rank_off = nullptr;              // (max_depth + 1) * rank_G
-  int* d_totals = nullptr;                // kMaxDepth + 3
+  unsigned long long* d_plane = nullptr;  // 2 x (max_depth + 1) * rank_G: node flags, then odd-group markers
+  int* d_rank_off = nullptr;              // 2 x (max_depth + 1) * rank_G
+  int* d_totals = nullptr;                // 2 x (kMaxDepth + 3): nodes per level, odd groups per level
+  int* d_level_real = nullptr;            // kMaxDepth + 3: real nodes above every level (ids have holes)
+  int* d_last_tmp = nullptr;              // capacity: end of every node's body range, by provisional id
   int rank_G = 0;                         // groups of 64 bodies at max_particles
   int node_limit = 0;                     // nbody_hip_tree_limit_nodes: 0 = the bound on the node count
   TreeArrays t{};
@@ -1272,7 +1297,7 @@ struct nbody_hip_tree {
 static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
   void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
-                  g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, g->d_totals,
+                  g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, g->d_totals, g->d_level_real, g->d_last_tmp,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
   for (void* p : ptrs) (void)hipFree(p);
@@ -1291,16 +1316,18 @@ static hipError_t dmalloc(T** p, size_t count) {
 // arrays, the sort / scan scratch and the node arrays
 static int tree_alloc_nodes(nbody_hip_tree* g) {
   void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
-                  g->d_keys_a, g->d_keys_b, g->d_plane, g->d_rank_off, g->d_tmp};
+                  g->d_keys_a, g->d_keys_b, g->d_plane, g->d_rank_off, g->d_last_tmp, g->d_tmp};
   for (void* p : ptrs) (void)hipFree(p);
   g->t = TreeArrays{};
   g->d_keys_a = g->d_keys_b = nullptr;
   g->d_plane = nullptr;
   g->d_rank_off = nullptr;
+  g->d_last_tmp = nullptr;
   g->d_tmp = nullptr;
   const size_t n = g->max_particles;
   // leaves <= n; internal nodes per level <= n / (leaf_max + 1)
-  size_t cap = n + (size_t)(g->max_depth + 1) * (n / (size_t)(g->leaf_max + 1) + 1) + 16;
+  // leaves <= n; internal nodes per level <= n / (leaf_max + 1), each with at most one padding id for its children
+  size_t cap = n + 2 * (size_t)(g->max_depth + 1) * (n / (size_t)(g->leaf_max + 1) + 1) + 16;
   // 28-bit child ids.  A tree that would need more nodes than the arrays hold is cut where the numbering passes the
   // capacity: the nodes beyond do not exist, their parents become leaves of several bodies (exact body-by-body
   // interactions; tree_fill_kernel / store_node flag them from the UNCLAMPED node total) -- slower, never wrong.
@@ -1308,8 +1335,8 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   if (g->node_limit > 0 && (size_t)g->node_limit < cap) cap = (size_t)g->node_limit;
   g->capacity = (int)cap;
   const size_t kbytes = n * (g->wide() ? sizeof(unsigned long long) : sizeof(unsigned int));
-  g->rank_G = (int)((n + 63) / 64);
-  const size_t nrank = (size_t)(g->max_depth + 1) * (size_t)g->rank_G;
+  g->rank_G = (int)((n + 64) / 64);  // positions 0 .. n (a marker may sit one past the last body)
+  const size_t nrank = 2 * (size_t)(g->max_depth + 1) * (size_t)g->rank_G;
   hipError_t e = hipMalloc(&g->d_keys_a, kbytes);
   if (e == hipSuccess) e = hipMalloc(&g->d_keys_b, kbytes);
   if (e == hipSuccess) e = dmalloc(&g->d_plane, nrank);
@@ -1327,6 +1354,7 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
     g->tmp_bytes = t1;
     if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
   }
+  if (e == hipSuccess) e = dmalloc(&g->d_last_tmp, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.first, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.last, cap);
   if (e == hipSuccess) e = dmalloc(&g->t.child0, cap);
@@ -1359,7 +1387,8 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   hipError_t e = dmalloc(&g->d_enc, 16);
   if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
-  if (e == hipSuccess) e = dmalloc(&g->d_totals, kMaxDepth + 3);
+  if (e == hipSuccess) e = dmalloc(&g->d_totals, 2 * (kMaxDepth + 3));
+  if (e == hipSuccess) e = dmalloc(&g->d_level_real, kMaxDepth + 3);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
   for (hipEvent_t* ev : {&g->ev_fork, &g->ev_join, &g->ev_plan})
     if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -1493,10 +1522,15 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
     NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
     unsigned int* lvlmask = reinterpret_cast<unsigned int*>(g->d_idx_a);  // idx_a is free after the sort
-    // the ranks are laid out for THIS build's body count: G groups of 64 (<= rank_G, the allocation)
-    const int G = (ni + 63) / 64;
-    hipLaunchKernelGGL(tree_flags_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, G);
+    // the ranks are laid out for THIS build's body count: G groups of 64 over the positions 0 .. ni
+    const int G = (ni + 64) / 64;
+    const size_t tbl = (size_t)levels * (size_t)G;
+    unsigned long long* odd_plane = g->d_plane + tbl;
+    int* odd_off = g->d_rank_off + tbl;
+    int* odd_totals = g->d_totals + (kMaxDepth + 3);
+    NBH_HIP(hipMemsetAsync(odd_plane, 0, tbl * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(tree_flags_kernel<K>, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, kb, ni,
+                       g->max_depth, g->leaf_max, lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, G);
     if (fused && side_ok) {
       // the prefix sums of the sorted bodies only feed the monopole pass: beside the ranks + fill pass
       const int pblocks = ni / kPrefixBlock + 1;
@@ -1509,12 +1543,17 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
       NBH_HIP(hipEventRecord(g->ev_join, g->side));
       prefix_forked = true;
     }
-    hipLaunchKernelGGL(level_scan_kernel, dim3(levels), dim3(kScanBlock), 0, st, g->d_rank_off, G, g->d_totals);
-    NBH_LAUNCH_CHECK();
-    const LevelRanks lr{g->d_plane, g->d_rank_off, G};
-    hipLaunchKernelGGL((tree_fill_kernel<K, false>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->t, g->capacity,
-                       g->d_level_base, g->d_sorted, PrefixSums{nullptr, nullptr}, g->d_root);
+    const LevelRanks lr{g->d_plane, g->d_rank_off, G}, odd{odd_plane, odd_off, G};
+    // node ranks -> body ranges + odd-group markers -> marker ranks -> fill
+    hipLaunchKernelGGL(level_scan_kernel, dim3(levels, 1), dim3(kScanBlock), 0, st, g->d_plane, g->d_rank_off, g->d_totals,
+                       odd_plane, odd_off, odd_totals, G);
+    hipLaunchKernelGGL(tree_span_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                       reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->capacity, g->d_last_tmp, odd_plane);
+    hipLaunchKernelGGL(level_scan_kernel, dim3(levels, 1), dim3(kScanBlock), 0, st, odd_plane, odd_off, odd_totals,
+                       odd_plane, odd_off, odd_totals, G);
+    hipLaunchKernelGGL(tree_fill_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                       reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, odd, g->d_totals, odd_totals, g->d_last_tmp,
+                       g->t, g->capacity, g->d_level_base, g->d_level_real);
     NBH_LAUNCH_CHECK();
     return NBODY_HIP_OK;
   };
@@ -1539,10 +1578,9 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
       hipLaunchKernelGGL(prefix_bodies_kernel, dim3(pblocks), dim3(kPrefixBlock), 0, st, g->d_sorted, ni, g->d_prefix, btot);
       hipLaunchKernelGGL(prefix_blocks_kernel, dim3(1), dim3(kPrefixBlock), 0, st, pblocks, btot, boff);
     }
-    // the node count is only known on the device: one thread per possible node of a tree of ni bodies
-    const size_t node_bound = std::min((size_t)g->capacity,
-                                       n + (size_t)levels * (n / (size_t)(g->leaf_max + 1) + 1) + 16);
-    hipLaunchKernelGGL(prefix_monopole_kernel, dim3((unsigned)((node_bound + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+    // (about two ids per body in practice; a fixed grid strides over whatever the numbering arrived at)
+    const size_t want = (2 * n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(prefix_monopole_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(want, 1), 16384)), dim3(kBlock), 0, st,
                        g->d_level_base, g->max_depth, g->d_sorted, PrefixSums{g->d_prefix, boff}, g->d_root, g->t);
   } else {
     // monopoles bottom-up: wide levels one launch each, the narrow top in a single workgroup
@@ -1756,9 +1794,18 @@ extern "C" int nbody_hip_tree_stats(nbody_hip_tree* g, int* node_count, float* r
   NBH_NOT_CAPTURABLE(ctx, "tree inspection");
   NBH_HIP(hipSetDevice(ctx->device));
   NBH_HIP(hipStreamSynchronize(ctx->stream));
-  int lb[kMaxDepth + 3];
-  NBH_HIP(hipMemcpy(lb, g->d_level_base, sizeof(lb), hipMemcpyDeviceToHost));
-  if (node_count) *node_count = lb[g->max_depth + 1];
+  // ids have holes (even-aligned sibling groups): what is reported is the number of NODES, per level and in all
+  int lb[kMaxDepth + 3], ids[kMaxDepth + 3];
+  NBH_HIP(hipMemcpy(lb, g->d_level_real, sizeof(lb), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(ids, g->d_level_base, sizeof(ids), hipMemcpyDeviceToHost));
+  int nodes = lb[g->max_depth + 1];
+  if (ids[kMaxDepth + 2] > g->capacity) {  // the tree was cut at the capacity: count what exists
+    std::vector<int> first((size_t)g->capacity);
+    NBH_HIP(hipMemcpy(first.data(), g->t.first, first.size() * sizeof(int), hipMemcpyDeviceToHost));
+    nodes = 0;
+    for (int nid = 0; nid < ids[g->max_depth + 1]; nid++) nodes += first[nid] >= 0;
+  }
+  if (node_count) *node_count = nodes;
   if (level_base_out)
     for (int k = 0; k < NBODY_HIP_TREE_LEVELS; k++) level_base_out[k] = k <= g->max_depth + 1 ? lb[k] : lb[g->max_depth + 1];
   if (root_mass) {
@@ -1783,18 +1830,25 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
   NBH_HIP(hipStreamSynchronize(ctx->stream));
   int lb[kMaxDepth + 3];
   NBH_HIP(hipMemcpy(lb, g->d_level_base, sizeof(lb), hipMemcpyDeviceToHost));
-  const int count = lb[g->max_depth + 1];
+  const int nids = lb[g->max_depth + 1];  // ids in use, holes included
   const int n = (int)g->built_count;
   if (sorted_indices)
     NBH_HIP(hipMemcpy(sorted_indices, g->d_idx_b, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   if (!host_nodes) return NBODY_HIP_OK;
+  // the engine's ids have holes (padding of odd sibling groups, nodes cut off by the capacity): the reference's
+  // array has none, so ids are compacted here and the child links rewritten
+  std::vector<int> first_of(nids), compact(nids, -1);
+  NBH_HIP(hipMemcpy(first_of.data(), g->t.first, (size_t)nids * sizeof(int), hipMemcpyDeviceToHost));
+  int count = 0;
+  for (int nid = 0; nid < nids; nid++)
+    if (first_of[nid] >= 0) compact[nid] = count++;
   if (capacity_nodes < count)
     return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "node buffer too small: %d < %d", capacity_nodes, count);
-  std::vector<NodeRec> rec(count);
+  std::vector<NodeRec> rec(nids);
   std::vector<unsigned long long> keys(n);  // 30-bit keys widened: one code path below
   std::vector<int> idx(n);
   TreeRoot root;
-  NBH_HIP(hipMemcpy(rec.data(), g->t.rec, (size_t)count * sizeof(NodeRec), hipMemcpyDeviceToHost));
+  NBH_HIP(hipMemcpy(rec.data(), g->t.rec, (size_t)nids * sizeof(NodeRec), hipMemcpyDeviceToHost));
   const int axis_bits = g->wide() ? 21 : 10;
   if (g->wide()) {
     NBH_HIP(hipMemcpy(keys.data(), g->d_keys_b, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1807,9 +1861,10 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
   NBH_HIP(hipMemcpy(&root, g->d_root, sizeof(root), hipMemcpyDeviceToHost));
   RefOctreeNode* out = static_cast<RefOctreeNode*>(host_nodes);
   int level = 0;
-  for (int nid = 0; nid < count; nid++) {
+  for (int nid = 0; nid < nids; nid++) {
     while (level < g->max_depth && nid >= lb[level + 1]) level++;
-    RefOctreeNode& o = out[nid];
+    if (compact[nid] < 0) continue;
+    RefOctreeNode& o = out[compact[nid]];
     const int first = rec[nid].first, cnt = rec[nid].count;
     const unsigned int ci = rec[nid].child;
     const unsigned long long k = keys[first];
@@ -1832,7 +1887,7 @@ extern "C" int nbody_hip_tree_copy_nodes(nbody_hip_tree* g, void* host_nodes, in
     if (!o.is_leaf) {
       const int c0 = (int)(ci & 0x0fffffffu), nc = (int)(ci >> 28);
       const int shift = 3 * axis_bits - 3 - 3 * level;
-      for (int c = c0; c < c0 + nc; c++) o.children[(keys[rec[c].first] >> shift) & 7ull] = c;
+      for (int c = c0; c < c0 + nc; c++) o.children[(keys[rec[c].first] >> shift) & 7ull] = compact[c];
     }
   }
   return NBODY_HIP_OK;
