@@ -328,7 +328,10 @@ NBODY_HIP_API int nbody_hip_tree_tuning(nbody_hip_tree* tree, int replicas, int 
 /* Form of the walk without replicas: 1 = plain (one sibling node per step), 2 = pair walk (two sibling nodes per
  * packed instruction, node records as pair blocks; same interaction lists, a sibling group's fp32 sum formed as
  * (even siblings) + (odd siblings)), its waves scheduled longest-first from the node visits the previous walk
- * recorded; 3 = pair walk in plain order; 0 = automatic (2).  Results do not depend on the schedule. */
+ * recorded; 3 = pair walk in plain order; 0 = automatic (2).  Results do not depend on the schedule.
+ * The pair walk needs the even-aligned node ids a build gives trees of >= 98,304 bodies (smaller trees are walked with
+ * replicas of the plain walk and keep plain ids); to force it on a smaller tree set the form BEFORE the build -- asking
+ * for it afterwards fails with NBODY_HIP_ERR_STATE. */
 NBODY_HIP_API int nbody_hip_tree_walk_form(nbody_hip_tree* tree, int form);
 /* Test / stress hook: cap the node arrays at `max_nodes` (0 = the bound on the node count; the arrays also stop
  * at 2^28 - 1 nodes, the width of a child link).  A tree that would need more nodes is cut where the numbering

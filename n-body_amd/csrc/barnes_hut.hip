@@ -432,7 +432,9 @@ __device__ __forceinline__ void mark_hole(const TreeArrays& t, int hole) {
   q[10] = 0u;
 }
 
-template <class K>
+// ALIGNED = false (trees that will not be walked by the pair kernel: fewer than kPairFrom bodies): plain ranks, no
+// padding, no span pass -- the body ranges are searched here (the small-tree build is launch-bound: three launches less)
+template <class K, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__ keys,
                                                            int n, int max_depth, int leaf_max,
                                                            const unsigned int* __restrict__ lvlmask,
@@ -447,12 +449,12 @@ __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__
     int run = 0, idrun = 0;
     for (int L = 0; L <= max_depth; L++) {
       ubase[L] = run;
-      base[L] = idrun;
+      base[L] = ALIGNED ? idrun : run;
       run += totals[L];
       idrun += L == 0 ? 2 : totals[L] + odd_totals[L];  // the root's slot 1 is a hole; every other level is even
     }
     ubase[max_depth + 1] = run;
-    base[max_depth + 1] = idrun;
+    base[max_depth + 1] = ALIGNED ? idrun : run;
   }
   __syncthreads();
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -462,18 +464,38 @@ __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__
   }
   if (i == 0) {
     level_base[kMaxDepth + 2] = base[max_depth + 1];  // the UNCLAMPED id total (TreeArrays::node_total)
-    if (1 < capacity) mark_hole(t, 1);                 // the hole beside the root
+    if (ALIGNED && 1 < capacity) mark_hole(t, 1);      // the hole beside the root
   }
   if (i >= n) return;
   unsigned int m = lvlmask[i];
+  [[maybe_unused]] const K key = keys[i];
   while (m) {
     const int L = __ffs(m) - 1;
     m &= m - 1;
     const int rk = lr.rank(L, i);
     const int pid = ubase[L] + rk - 1;
-    const int nid = base[L] + rk - 1 + (L > 0 ? odd.rank(L, i) : 0);
+    const int nid = ALIGNED ? base[L] + rk - 1 + (L > 0 ? odd.rank(L, i) : 0) : pid;
     if (nid >= capacity || pid >= capacity) continue;  // beyond the node arrays: this node does not exist (its parent is a leaf)
-    const int last = last_tmp[pid];
+    int last;
+    if constexpr (ALIGNED) {
+      last = last_tmp[pid];
+    } else {
+      // one past the last body of the group: first j > i with another prefix
+      last = n;
+      if (L > 0) {
+        const int shift = KeyTraits<K>::kTop - 3 * L;
+        const K prefix = key >> shift;
+        int lo = i + 1, hi = n;
+        int step = 1;  // gallop first: groups are short (a node of a deep level holds a handful of bodies)
+        while (lo + step < hi && (keys[lo + step - 1] >> shift) == prefix) { lo += step; step <<= 1; }
+        hi = min(hi, lo + step);
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if ((keys[mid] >> shift) == prefix) lo = mid + 1; else hi = mid;
+        }
+        last = lo;
+      }
+    }
     t.first[nid] = i;
     t.last[nid] = last;
     int c0 = -1, c1 = -1;
@@ -481,10 +503,10 @@ __global__ __launch_bounds__(kBlock) void tree_fill_kernel(const K* __restrict__
       // children: the flagged bodies of level L + 1 inside [i, last); body i is always one of them
       const int r0 = lr.rank(L + 1, i);
       const int cn = lr.rank(L + 1, last - 1) - r0 + 1;
-      c0 = base[L + 1] + r0 - 1 + odd.rank(L + 1, i);
+      c0 = base[L + 1] + r0 - 1 + (ALIGNED ? odd.rank(L + 1, i) : 0);
       c1 = c0 + cn - 1;
       if (c1 >= capacity || ubase[L + 1] + r0 - 1 + cn - 1 >= capacity) { c0 = -1; c1 = -1; }
-      else if ((cn & 1) && c1 + 1 < capacity) mark_hole(t, c1 + 1);  // the hole that pads an odd group
+      else if (ALIGNED && (cn & 1) && c1 + 1 < capacity) mark_hole(t, c1 + 1);  // the hole that pads an odd group
     }
     t.child0[nid] = c0;
     t.child_last[nid] = c1;
@@ -1290,6 +1312,7 @@ struct nbody_hip_tree {
   // events on the context's stream; not used while a step graph is being recorded.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_plan = nullptr;
+  bool aligned = false;          // the last build padded the sibling groups to even ids (what the pair walk needs)
   bool plan_pending = false;     // the schedule for the full range was queued on the side stream by the last build
   int plan_n = -1, plan_cap = 0;
 };
@@ -1528,7 +1551,10 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     unsigned long long* odd_plane = g->d_plane + tbl;
     int* odd_off = g->d_rank_off + tbl;
     int* odd_totals = g->d_totals + (kMaxDepth + 3);
-    NBH_HIP(hipMemsetAsync(odd_plane, 0, tbl * sizeof(unsigned long long), st));
+    // even-aligned sibling groups are what the pair walk needs: trees it will walk (from kPairFrom bodies, or when that
+    // walk form is forced) get them, smaller trees keep plain ids and save three launches
+    g->aligned = ni >= kPairFrom || g->tune_form == 2;
+    if (g->aligned) NBH_HIP(hipMemsetAsync(odd_plane, 0, tbl * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, kb, ni,
                        g->max_depth, g->leaf_max, lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, G);
     if (fused && side_ok) {
@@ -1544,16 +1570,22 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
       prefix_forked = true;
     }
     const LevelRanks lr{g->d_plane, g->d_rank_off, G}, odd{odd_plane, odd_off, G};
-    // node ranks -> body ranges + odd-group markers -> marker ranks -> fill
+    // node ranks -> (aligned: body ranges + odd-group markers -> marker ranks) -> fill
     hipLaunchKernelGGL(level_scan_kernel, dim3(levels, 1), dim3(kScanBlock), 0, st, g->d_plane, g->d_rank_off, g->d_totals,
                        odd_plane, odd_off, odd_totals, G);
-    hipLaunchKernelGGL(tree_span_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->capacity, g->d_last_tmp, odd_plane);
-    hipLaunchKernelGGL(level_scan_kernel, dim3(levels, 1), dim3(kScanBlock), 0, st, odd_plane, odd_off, odd_totals,
-                       odd_plane, odd_off, odd_totals, G);
-    hipLaunchKernelGGL(tree_fill_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                       reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, odd, g->d_totals, odd_totals, g->d_last_tmp,
-                       g->t, g->capacity, g->d_level_base, g->d_level_real);
+    if (g->aligned) {
+      hipLaunchKernelGGL(tree_span_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->capacity, g->d_last_tmp, odd_plane);
+      hipLaunchKernelGGL(level_scan_kernel, dim3(levels, 1), dim3(kScanBlock), 0, st, odd_plane, odd_off, odd_totals,
+                         odd_plane, odd_off, odd_totals, G);
+      hipLaunchKernelGGL((tree_fill_kernel<K, true>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, odd, g->d_totals, odd_totals, g->d_last_tmp,
+                         g->t, g->capacity, g->d_level_base, g->d_level_real);
+    } else {
+      hipLaunchKernelGGL((tree_fill_kernel<K, false>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
+                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, odd, g->d_totals, odd_totals, g->d_last_tmp,
+                         g->t, g->capacity, g->d_level_base, g->d_level_real);
+    }
     NBH_LAUNCH_CHECK();
     return NBODY_HIP_OK;
   };
@@ -1671,8 +1703,15 @@ static int tree_walk(nbody_hip_tree* g, int first, int count, float theta, float
   int unit_max = (int)(g->built_count / units);
   if (unit_max < 1) unit_max = 1;
   const bool guard = eps2 < 1e-12f;
-  // walk without replicas: the pair walk unless the plain one is asked for
+  // walk without replicas: the pair walk unless the plain one is asked for -- or the tree was built with plain ids
+  // (fewer than kPairFrom bodies and the pair form not forced when it was built): its pair blocks are not group-aligned
   int form = g->tune_form > 0 ? g->tune_form : 2;
+  if (!g->aligned) {
+    if (g->tune_form == 2)
+      return NBH_FAIL(NBODY_HIP_ERR_STATE, "the pair walk was asked for after a build with plain node ids (%zu bodies < %d): "
+                      "set the walk form before the build", g->built_count, kPairFrom);
+    form = 1;
+  }
 #define NBH_BH_LAUNCH(GD, SP, GRID)                                                                       \
   hipLaunchKernelGGL((bh_traverse_kernel<GD, SP>), GRID, dim3(kBlock), 0, ctx->stream, g->t.rec, g->d_sorted, \
                      g->d_idx_b, first, n, theta2, eps2, G, ax, ay, az, acc4, visits,                     \

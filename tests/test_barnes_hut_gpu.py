@@ -293,6 +293,7 @@ def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     d, _ = to_device(nb, ic)
     tree = nb.BarnesHutTree(n)
     tree.setParams(max_depth, leaf_max)
+    tree.walkForm(2)   # before the build: small trees get the even-aligned node ids of the pair walk only on request
     tree.build(d)
     tree.tuning(1, 0)
     tree.walkForm(1)
@@ -320,6 +321,16 @@ def test_pair_walk_equals_plain_walk(nb, ctx, n, eps, max_depth, leaf_max):
     tree.countVisits(False)
     with pytest.raises(nb.ValidationException):
         tree.walkForm(4)
+    if n < 98304:   # a small tree built with plain ids refuses the pair walk instead of walking misaligned blocks
+        tree.walkForm(0)
+        tree.build(d)
+        tree.computeForces(d, 0.5, 1.0, eps)
+        auto = acc_of(d)
+        assert rel_err(auto, plain).max() < 1e-5
+        tree.walkForm(2)
+        with pytest.raises(nb.NBodyError, match="before the build"):
+            tree.computeForces(d, 0.5, 1.0, eps)
+        tree.walkForm(0)
 
 
 # the cost-ordered schedule under extreme skew: a compact core inside a wide box (a few waves carry most of the
