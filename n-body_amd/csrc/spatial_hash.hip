@@ -582,7 +582,10 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     const long long cell = cell0 + c;
     if (c < KC && cell < cell_end) {
       if (r < 9) {
-        const int cx = (int)(cell % gx), cy = (int)((cell / gx) % gy), cz = (int)(cell / ((long long)gx * gy));
+        // (32-bit: a grid holds at most 1e8 cells; the 64-bit divisions this replaces were ~100 instructions each)
+        const unsigned int c32 = (unsigned int)cell, layer = (unsigned int)gx * (unsigned int)gy;
+        const unsigned int uz = c32 / layer, rem = c32 - uz * layer, uy = rem / (unsigned int)gx;
+        const int cx = (int)(rem - uy * (unsigned int)gx), cy = (int)uy, cz = (int)uz;
         const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
         if (yy >= 0 && yy < gy && zz >= 0 && zz < gz && !(HALF && r < 4)) {
           const long long base = ((long long)zz * gy + yy) * gx;
