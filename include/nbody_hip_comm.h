@@ -114,6 +114,42 @@ NBODY_HIP_API int nbody_hip_sharded_direct_energies(nbody_hip_sharded_direct* s,
  * compute stream, which waits for the null stream of `d`'s device at entry and is waited for by it at exit. */
 NBODY_HIP_API int nbody_hip_sharded_direct_compute_forces(nbody_hip_sharded_direct* s, nbody_particle_data* d);
 
+/* ---- the sharded spatial hash (BASELINE config 5) --------------------------------------------------------------
+ * z-slabs of cells over the communicator's ranks (the linear cell id x + y gx + z gx gy, ref: force_spatial_hash.cu:48,
+ * makes a range of z layers a contiguous block of the cell-ordered body list).  One force evaluation: all-reduce of
+ * the bounding box -> ONE partition pass (layer and owner of every body, the bodies that change owner as 64-byte
+ * rows, send matrix, layer histogram) -> all-reduce (sum) -> the step's one host synchronisation -> the migrating
+ * rows travel point to point, arrivals fill the vacated slots -> own grid -> the two boundary layers travel to the
+ * neighbours (16 B per body) WHILE the wave-per-cell kernel evaluates own x own -> a grid over the received layers,
+ * the boundary layers against it.  Same results as the single grid (ref: SpatialHashCalculator::computeForces,
+ * force_spatial_hash.cu:334-377) up to the summation order of the boundary bodies.  csrc/sharded_hash.hip. */
+typedef struct nbody_hip_sharded_hash nbody_hip_sharded_hash;
+
+NBODY_HIP_API int nbody_hip_sharded_hash_create(nbody_hip_comm* comm, size_t n, float G, float eps, float cell_size,
+                                                float cutoff, nbody_hip_sharded_hash** out);
+NBODY_HIP_API int nbody_hip_sharded_hash_destroy(nbody_hip_sharded_hash* s);
+/* HOST arrays of the whole system (n floats each; velocities may be NULL): every local rank keeps the bodies of its
+ * slab of the initial global grid (every process passes the same arrays).  Blocking. */
+NBODY_HIP_API int nbody_hip_sharded_hash_set_state(nbody_hip_sharded_hash* s, const float* x, const float* y,
+                                                   const float* z, const float* mass, const float* vx,
+                                                   const float* vy, const float* vz);
+NBODY_HIP_API int nbody_hip_sharded_hash_forces(nbody_hip_sharded_hash* s);              /* a(0) */
+/* `steps` Velocity-Verlet steps; each contains one host synchronisation (the grid size decides validity, as in the
+ * reference), so the call returns when the last step's exchange is done and its tail is queued. */
+NBODY_HIP_API int nbody_hip_sharded_hash_step(nbody_hip_sharded_hash* s, float dt, int steps);
+NBODY_HIP_API int nbody_hip_sharded_hash_time_steps(nbody_hip_sharded_hash* s, float dt, int warmup, int steps,
+                                                    float* ms_per_step);
+NBODY_HIP_API int nbody_hip_sharded_hash_synchronize(nbody_hip_sharded_hash* s);
+/* HOST arrays of n floats indexed by the bodies' GLOBAL ids (any may be NULL); each process fills the rows of the
+ * bodies its local ranks hold.  Blocking. */
+NBODY_HIP_API int nbody_hip_sharded_hash_get_state(nbody_hip_sharded_hash* s, float* x, float* y, float* z, float* vx,
+                                                   float* vy, float* vz, float* ax, float* ay, float* az);
+/* Of the last evaluation (any output may be NULL): global grid dims; 1 if every rank took the overlapped two-grid
+ * path; bodies that changed owner and halo bodies received, summed over the local ranks; bodies per local rank. */
+NBODY_HIP_API int nbody_hip_sharded_hash_info(const nbody_hip_sharded_hash* s, int dims[3], int* two_grid,
+                                              unsigned long long* migrated, unsigned long long* halo_bodies,
+                                              unsigned long long local_counts[NBODY_HIP_MAX_RANKS]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,6 +165,15 @@ PROTOTYPES = {
     "nbody_hip_sharded_direct_get_state": (C.c_int, [_P] * 10 + [C.c_int]),
     "nbody_hip_sharded_direct_energies": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nbody_hip_sharded_direct_compute_forces": (C.c_int, [_P, _PD]),
+    "nbody_hip_sharded_hash_create": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(_P)]),
+    "nbody_hip_sharded_hash_destroy": (C.c_int, [_P]),
+    "nbody_hip_sharded_hash_set_state": (C.c_int, [_P] * 8),
+    "nbody_hip_sharded_hash_forces": (C.c_int, [_P]),
+    "nbody_hip_sharded_hash_step": (C.c_int, [_P, C.c_float, C.c_int]),
+    "nbody_hip_sharded_hash_time_steps": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nbody_hip_sharded_hash_synchronize": (C.c_int, [_P]),
+    "nbody_hip_sharded_hash_get_state": (C.c_int, [_P] * 10),
+    "nbody_hip_sharded_hash_info": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _P]),
 }
 
 _lib = None

@@ -26,33 +26,15 @@
 // WAR hazards: a receive block is rewritten by a sender only after the sender passed "pairs" of the new step, i.e.
 // after it saw the owner's ev_gather of the new step, which the owner records after its own finalize of the old one.
 
-#include <dlfcn.h>
-#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time (no link dependency)
-
 #include <cstring>
 #include <vector>
 
-#include "common.h"
-#include "nbody_hip_comm.h"
+#include "comm.h"
 
 namespace nbh {
 
 // ---- RCCL, resolved at run time -----------------------------------------------------------------------------------
-struct Rccl {
-  void* so = nullptr;
-  decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&::ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&::ncclCommInitAll) CommInitAll = nullptr;
-  decltype(&::ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&::ncclAllGather) AllGather = nullptr;
-  decltype(&::ncclSend) Send = nullptr;
-  decltype(&::ncclRecv) Recv = nullptr;
-  decltype(&::ncclGroupStart) GroupStart = nullptr;
-  decltype(&::ncclGroupEnd) GroupEnd = nullptr;
-  decltype(&::ncclGetErrorString) GetErrorString = nullptr;
-};
-
-static Rccl* rccl_load() {
+Rccl* rccl_load() {
   static Rccl r;
   static bool tried = false;
   if (tried) return r.so ? &r : nullptr;
@@ -71,6 +53,7 @@ static Rccl* rccl_load() {
   NBH_SYM(CommInitAll, "ncclCommInitAll");
   NBH_SYM(CommDestroy, "ncclCommDestroy");
   NBH_SYM(AllGather, "ncclAllGather");
+  NBH_SYM(AllReduce, "ncclAllReduce");
   NBH_SYM(Send, "ncclSend");
   NBH_SYM(Recv, "ncclRecv");
   NBH_SYM(GroupStart, "ncclGroupStart");
@@ -84,13 +67,6 @@ static Rccl* rccl_load() {
   r.so = so;
   return &r;
 }
-
-#define NBH_NCCL(api, call)                                                                                      \
-  do {                                                                                                           \
-    ncclResult_t r_ = (call);                                                                                    \
-    if (r_ != ncclSuccess)                                                                                       \
-      return NBH_FAIL((nbody_hip_status)NBODY_HIP_ERR_COMM, "%s: %s", #call, (api)->GetErrorString(r_));         \
-  } while (0)
 
 static_assert(sizeof(nbody_hip_comm_id) == sizeof(ncclUniqueId), "nbody_hip_comm_id must hold an ncclUniqueId");
 
@@ -131,17 +107,6 @@ __global__ __launch_bounds__(kBlock) void shard_finalize_kernel(const float4* __
 using namespace nbh;
 
 // ---- communicators ------------------------------------------------------------------------------------------------
-struct nbody_hip_comm {
-  int world = 0;
-  int transport = NBODY_HIP_TRANSPORT_P2P;
-  struct Member {
-    int rank = 0, device = 0;
-    ncclComm_t nccl = nullptr;
-  };
-  std::vector<Member> local;  // ranks living in this process, ascending
-  bool all_local() const { return (int)local.size() == world; }
-};
-
 extern "C" int nbody_hip_shard_bounds(size_t n, int world, int rank, size_t* shard, size_t* lo, size_t* hi) {
   if (world < 1 || rank < 0 || rank >= world) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "rank %d outside world %d", rank, world);
   const size_t s = (n + (size_t)world - 1) / (size_t)world;

@@ -154,3 +154,62 @@ class ShardedDirect:
             self.close()
         except Exception:
             pass
+
+
+class ShardedHash:
+    """nbody_hip_sharded_hash_*: BASELINE config 5 (z-slab shards, migration, halo exchange) behind the C ABI."""
+
+    def __init__(self, comm: Comm, n: int, G: float, eps: float, cell_size: float, cutoff: float):
+        self.comm, self.n = comm, int(n)
+        self._lib = load()
+        self._h = C.c_void_p()
+        check(self._lib.nbody_hip_sharded_hash_create(comm._h, n, G, eps, cell_size, cutoff, C.byref(self._h)))
+
+    def set_state(self, ic: dict):
+        a = [_f(ic[k]) for k in ("pos_x", "pos_y", "pos_z", "mass")]
+        v = [_f(ic.get(k)) for k in ("vel_x", "vel_y", "vel_z")]
+        assert all(x.size == self.n for x in a)
+        if any(x is None for x in v):
+            v = [None, None, None]
+        check(self._lib.nbody_hip_sharded_hash_set_state(self._h, *[x.ctypes.data if x is not None else None for x in a + v]))
+
+    def forces(self):
+        check(self._lib.nbody_hip_sharded_hash_forces(self._h))
+
+    def step(self, dt: float, steps: int = 1):
+        check(self._lib.nbody_hip_sharded_hash_step(self._h, dt, steps))
+
+    def time_steps(self, dt: float, warmup: int, steps: int) -> float:
+        ms = C.c_float()
+        check(self._lib.nbody_hip_sharded_hash_time_steps(self._h, dt, warmup, steps, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        check(self._lib.nbody_hip_sharded_hash_synchronize(self._h))
+
+    def get_state(self, what=("pos", "vel", "acc")) -> dict:
+        """numpy arrays of the whole system by global body id (rows of bodies held by other processes stay 0)"""
+        names = [f"{w}_{c}" for w in ("pos", "vel", "acc") for c in "xyz"]
+        out = {k: np.zeros(self.n, np.float32) for k in names if k[:3] in what}
+        check(self._lib.nbody_hip_sharded_hash_get_state(self._h, *[out[k].ctypes.data if k in out else None for k in names]))
+        return out
+
+    def info(self) -> dict:
+        dims, tg = (C.c_int * 3)(), C.c_int()
+        mig, halo = C.c_ulonglong(), C.c_ulonglong()
+        counts = (C.c_ulonglong * MAX_RANKS)()
+        check(self._lib.nbody_hip_sharded_hash_info(self._h, dims, C.byref(tg), C.byref(mig), C.byref(halo), counts))
+        nl = self.comm.info()["nlocal"]
+        return {"dims": list(dims), "two_grid": bool(tg.value), "migrated": mig.value, "halo_bodies": halo.value,
+                "local_counts": list(counts[:nl])}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.nbody_hip_sharded_hash_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

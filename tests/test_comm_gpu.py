@@ -169,3 +169,101 @@ def test_plugin_form_through_integrator(nb, ctx, W):
     with pytest.raises(nb.ValidationException):
         small, _ = to_device(nb, nb.ic.plummer(100, seed=1))
         many.sys.compute_forces(small)
+
+
+# ---- BASELINE config 5 behind the C ABI: nbody_hip_sharded_hash_* (csrc/sharded_hash.hip) ------------------------------
+def _single_gpu_hash(nb, ic, G, eps, cell, cutoff, dt, steps):
+    d, _ = to_device(nb, ic)
+    fc = nb.SpatialHashCalculator(cell, cutoff)
+    fc.setGravitationalConstant(G)
+    fc.setSofteningParameter(eps)
+    fc.computeForces(d)
+    a0 = acc_of(d)
+    integ = nb.Integrator()
+    for _ in range(steps):
+        integ.integrate(d, fc, dt)
+    torch.cuda.synchronize()
+    return a0, {k: getattr(d, k).cpu().numpy() for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z",
+                                                          "acc_x", "acc_y", "acc_z")}, fc.getGrid().getGridDims()
+
+
+# z-slab shards on 1-8 VIRTUAL ranks of the test GPU: the accelerations of the first evaluation and the state after
+# several steps (with bodies migrating between slabs and halo layers exchanged every step) equal the single-GPU
+# spatial hash; cutoff <= cell and cutoff > cell (the reference's incomplete 27-cell search, reproduced); a grid too
+# sparse for the two-grid kernel takes the one-grid path; ranks without layers (gz < W)
+@pytest.mark.parametrize("W,n,half,cell,cutoff", [(1, 20000, 6.0, 1.0, 1.0), (2, 30000, 6.0, 1.0, 1.0), (3, 30000, 6.0, 1.0, 2.0),
+                                                  (4, 60000, 8.0, 1.0, 1.0), (8, 200000, 12.0, 1.0, 1.0), (4, 3000, 20.0, 1.0, 1.0),
+                                                  (8, 5000, 2.0, 1.0, 1.0)])
+def test_sharded_hash_virtual_ranks_equal_single_gpu(nb, oracle, ctx, W, n, half, cell, cutoff):
+    from nbody_amd.sharded import Comm, ShardedHash
+    G, eps, dt, steps = 1.2, 0.05, 2e-2, 4
+    ic = nb.ic.uniform_box(n, seed=100 + W, lo=-half, hi=half, min_mass=0.5, max_mass=1.5)
+    rng = np.random.default_rng(W)     # velocities that carry bodies across slab boundaries within a few steps
+    for k in ("vel_x", "vel_y", "vel_z"):
+        ic[k] = rng.normal(0.0, 3.0, n).astype(np.float32)
+    comm = Comm.init_all(W, [0] * W)
+    sysm = ShardedHash(comm, n, G, eps, cell, cutoff)
+    sysm.set_state(ic)
+    sysm.forces()
+    a_sh = np.stack([sysm.get_state(what=("acc",))[k] for k in ("acc_x", "acc_y", "acc_z")], 1)
+    a0, ref, dims = _single_gpu_hash(nb, ic, G, eps, cell, cutoff, dt, steps)
+    info = sysm.info()
+    assert tuple(info["dims"]) == tuple(dims) and sum(info["local_counts"]) == n
+    nz = np.linalg.norm(a0, axis=1) > 0
+    assert np.all(a_sh[~nz] == 0)
+    assert rel_err(a_sh[nz], a0[nz]).max() < TOL          # boundary bodies are summed in another order: fp rounding
+    eps2 = float(np.float32(eps) * np.float32(eps))
+    orc = np.stack(oracle.spatial_hash_forces(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], G, eps2, cell, cutoff), 1)
+    assert rel_err(a_sh[nz], orc[nz]).max() < 2e-5
+    migrated = 0
+    for _ in range(steps):
+        sysm.step(dt, 1)
+        migrated += sysm.info()["migrated"]
+    st = sysm.get_state()
+    for k in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert np.allclose(st[k], ref[k], rtol=2e-5, atol=2e-5), k
+    if W > 1 and n >= 20000:
+        assert migrated > 0 and sysm.info()["halo_bodies"] > 0
+    if half == 20.0:
+        assert not sysm.info()["two_grid"]                  # 41^3 cells for 3,000 bodies: the one-grid path
+    elif n >= 20000:
+        assert sysm.info()["two_grid"]
+    # reproducible run after run
+    again = ShardedHash(comm, n, G, eps, cell, cutoff)
+    again.set_state(ic)
+    again.forces()
+    again.step(dt, steps)
+    st2 = again.get_state()
+    for k in st:
+        assert np.array_equal(st[k], st2[k]), k
+    again.close(); sysm.close(); comm.close()
+
+
+def test_sharded_hash_one_rccl_rank_and_errors(nb, ctx):
+    from nbody_amd.sharded import TRANSPORT_RCCL, Comm, ShardedHash
+    n = 40000
+    ic = nb.ic.uniform_box(n, seed=7, lo=-7.0, hi=7.0)
+    comm = Comm.init_all(1, [0], TRANSPORT_RCCL)     # the RCCL all-reduces of the box and of the counts with one rank
+    a = ShardedHash(comm, n, 1.0, 0.05, 1.0, 1.0)
+    a.set_state(ic)
+    a.forces()
+    a.step(1e-2, 3)
+    ms = a.time_steps(1e-2, 1, 3)
+    assert 0 < ms < 100
+    p2p = Comm.init_all(1, [0])
+    b = ShardedHash(p2p, n, 1.0, 0.05, 1.0, 1.0)
+    b.set_state(ic)
+    b.forces()
+    b.step(1e-2, 7)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    with pytest.raises(nb.ValidationException):
+        ShardedHash(p2p, n, 1.0, 0.05, 0.0, 1.0)
+    far = dict(ic)
+    far["pos_x"] = ic["pos_x"].copy()
+    far["pos_x"][0] = 1.0e6                          # > 1e8 cells: "grid too large", as the reference's build
+    c = ShardedHash(p2p, n, 1.0, 0.05, 1.0, 1.0)
+    with pytest.raises(nb.ResourceException, match="too large"):
+        c.set_state(far)
+    a.close(); b.close(); c.close(); comm.close(); p2p.close()
