@@ -171,17 +171,42 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch, workload=N
     workload = workload or a.workload
     steps = steps or a.steps
     warmup = a.warmup if warmup is None else warmup
+    sync_system = None
     if workload == "hash":
         n = n_bodies or (a.n if a.n != (1 << 20) else 4194304)
         half = 0.5 * (n / 16.0) ** (1.0 / 3.0)  # 16 bodies per unit volume
         ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
         cell, cutoff, eps = 1.0, 1.0, 0.01
         if sharded:
-            sysm = ShardedHashSystem(ic, 1.0, eps, cell, cutoff, backend=HipBackend(ctx))
-            sysm.initial_forces()
-            step = lambda: sysm.step(dt)  # noqa: E731
-            path = ("z-slab shards: all-reduce bbox, one partition pass + all-reduce of counts, ONE host sync, all-to-all "
-                    "of the migrating bodies, halo all-to-all overlapped with the own x own force kernel")
+            csys, why = None, ""
+            if a.sharded_host == "cabi" and a.dist_backend == "nccl" and not a.one_device:
+                try:  # the whole step behind the C ABI (csrc/sharded_hash.hip), RCCL communicator made from C++
+                    from nbody_amd.sharded import Comm, ShardedHash
+                    comm = Comm.from_torch_distributed(torch.cuda.current_device())
+                    csys = ShardedHash(comm, n, 1.0, eps, cell, cutoff)
+                    csys.set_state(ic)
+                    csys.forces()
+                    csys.synchronize()
+                except Exception as e:
+                    why = f" (C-ABI host unavailable: {type(e).__name__}: {e})"
+                    csys = None
+                ok = torch.tensor([1 if csys is not None else 0], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    csys = None
+            if csys is not None:
+                step = lambda: csys.step(dt, 1)  # noqa: E731
+                sync_system = csys.synchronize
+                path = ("C ABI (nbody_hip_sharded_hash_step): z-slab shards; per step all-reduce of the box, one partition "
+                        "pass + all-reduce of the counts, ONE host sync, migrating bodies point to point, halo layers "
+                        "exchanged while the own x own force kernel runs")
+            else:
+                sysm = ShardedHashSystem(ic, 1.0, eps, cell, cutoff, backend=HipBackend(ctx))
+                sysm.initial_forces()
+                step = lambda: sysm.step(dt)  # noqa: E731
+                path = ("torch.distributed host: z-slab shards: all-reduce bbox, one partition pass + all-reduce of counts, "
+                        "ONE host sync, all-to-all of the migrating bodies, halo all-to-all overlapped with the own x own "
+                        "force kernel" + why)
         else:
             ps = nb.ParticleSystem()
             ps.initialize(nb.SimulationConfig(particle_count=n, force_method=nb.ForceMethod.SPATIAL_HASH, dt=dt,
@@ -209,6 +234,8 @@ def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch, workload=N
         name = f"two_galaxies_N{n}_barnes_hut_theta0.5_velocity_verlet"
 
     def barrier():
+        if sync_system is not None:  # the C-ABI system's own streams first
+            sync_system()
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()

@@ -309,6 +309,12 @@ NBODY_HIP_API int nbody_hip_slab_fill(nbody_hip_ctx* ctx, const float* rows, siz
  * all-reduce it).  ref: computeBoundingBoxKernel, force_barnes_hut.cu:66-110 */
 NBODY_HIP_API int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t count,
                                         float* bounds_device);
+/* The float4 drift of nbody_hip_drift_packed (x += v dt + a dt^2/2, integrator.cu:16-19) and the box of the NEW
+ * positions in ONE pass.  enc_device: 6 words private to the caller that hold the empty box {0xffffffff x3, 0 x3}
+ * before the FIRST call; every call leaves them re-armed.  Async. */
+NBODY_HIP_API int nbody_hip_drift_bbox_packed(nbody_hip_ctx* ctx, nbody_float4* posm, const nbody_float4* vel,
+                                              const nbody_float4* acc, size_t count, float dt,
+                                              unsigned int* enc_device, float* bounds_device);
 /* z cell coordinate (clamped to [0, gz-1]) of packed bodies on a grid with origin lo_z; DEVICE
  * int output.  ref: assignCellsKernel, force_spatial_hash.cu:28-49 */
 NBODY_HIP_API int nbody_hip_cell_z_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t count,

@@ -123,6 +123,7 @@ PROTOTYPES = {
                                            _P, _P, _P, _P, _P]),
     "nbody_hip_slab_fill": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P]),
     "nbody_hip_bbox_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "nbody_hip_drift_bbox_packed": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float, _P, _P]),
     "nbody_hip_cell_z_packed": (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, C.c_int, _P]),
     "nbody_hip_tree_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nbody_hip_tree_destroy": (C.c_int, [_P]),

@@ -60,6 +60,9 @@ __global__ __launch_bounds__(kBlock) void int_sum_kernel(PeerPtrs in, int count,
     out[i] = v;
   }
 }
+__global__ void box_flip_kernel(float* __restrict__ box) {  // {lo, hi} <-> {lo, -hi}
+  if (threadIdx.x >= 3 && threadIdx.x < 6) box[threadIdx.x] = -box[threadIdx.x];
+}
 __global__ void box_empty_kernel(float* __restrict__ box) {
   if (threadIdx.x < 6) box[threadIdx.x] = threadIdx.x < 3 ? 3.0e38f : -3.0e38f;
 }
@@ -87,10 +90,13 @@ struct HShard {
   float* rows = nullptr;
   int* holes = nullptr;
   size_t part_cap = 0;
-  int *stats = nullptr, *stats_sum = nullptr, *info = nullptr;  // W*W + kHistCap ints; 4 ints
-  float *box = nullptr, *gbox = nullptr;                          // 6 floats each
-  float* h_box = nullptr;                                         // pinned mirrors
-  int *h_stats = nullptr, *h_info = nullptr;
+  int* stats = nullptr;            // W*W + kHistCap ints: send matrix row block | layer histogram of this rank
+  // what the host reads once per evaluation, ONE block and one copy: stats_sum [nstats] | info [4] | gbox [6 floats]
+  int *sum_block = nullptr, *h_block = nullptr;  // device, pinned mirror
+  int *stats_sum = nullptr, *info = nullptr, *h_stats = nullptr, *h_info = nullptr;
+  float *gbox = nullptr, *h_box = nullptr;
+  float* box = nullptr;            // 6 floats: this rank's box
+  unsigned int* enc = nullptr;     // 6 ordered-int words of the fused drift + box pass (nbody_hip_drift_bbox_packed)
   // exchange buffers
   float* got = nullptr;
   size_t got_cap = 0;
@@ -138,12 +144,10 @@ static void hshard_release(HShard& x) {
   if (x.comm) (void)hipStreamSynchronize(x.comm);
   for (nbody_hip_grid* g : {x.g_own, x.g_halo, x.g_one})
     if (g) (void)nbody_hip_grid_destroy(g);
-  void* dev[] = {x.posm, x.vel, x.acc, x.acc2, x.gid, x.rows, x.holes, x.stats, x.stats_sum, x.info, x.box, x.gbox,
+  void* dev[] = {x.posm, x.vel, x.acc, x.acc2, x.gid, x.rows, x.holes, x.stats, x.sum_block, x.box, x.enc,
                  x.got, x.halo_out, x.halo_in, x.cat, x.cat_acc};
   for (void* p : dev) (void)hipFree(p);
-  if (x.h_box) (void)hipHostFree(x.h_box);
-  if (x.h_stats) (void)hipHostFree(x.h_stats);
-  if (x.h_info) (void)hipHostFree(x.h_info);
+  if (x.h_block) (void)hipHostFree(x.h_block);
   for (hipEvent_t e : {x.ev_a, x.ev_b, x.ev_c, x.ev_d, x.t0, x.t1})
     if (e) (void)hipEventDestroy(e);
   if (x.ctx) (void)nbody_hip_ctx_destroy(x.ctx);
@@ -194,13 +198,18 @@ extern "C" int nbody_hip_sharded_hash_create(nbody_hip_comm* comm, size_t n, flo
     if (e == hipSuccess) e = hipEventCreate(&x.t0);
     if (e == hipSuccess) e = hipEventCreate(&x.t1);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.stats), nstats * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.stats_sum), nstats * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.info), 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.sum_block), (nstats + 10) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.box), 6 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.gbox), 6 * sizeof(float));
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&x.h_box), 6 * sizeof(float), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&x.h_stats), nstats * sizeof(int), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&x.h_info), 4 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x.enc), 8 * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&x.h_block), (nstats + 10) * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) {
+      const unsigned int empty[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+      e = hipMemcpy(x.enc, empty, sizeof(empty), hipMemcpyHostToDevice);
+      x.stats_sum = x.sum_block;           x.h_stats = x.h_block;
+      x.info = x.sum_block + nstats;       x.h_info = x.h_block + nstats;
+      x.gbox = reinterpret_cast<float*>(x.sum_block + nstats + 4);
+      x.h_box = reinterpret_cast<float*>(x.h_block + nstats + 4);
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
       return fail(NBH_FAIL(e == hipErrorOutOfMemory ? NBODY_HIP_ERR_RESOURCE : NBODY_HIP_ERR_DEVICE,
@@ -301,7 +310,8 @@ extern "C" int nbody_hip_sharded_hash_set_state(nbody_hip_sharded_hash* s, const
 }
 
 // ---- one exchange + force evaluation: result in acc2 of every local rank -----------------------------------------
-static int hash_force_phase(nbody_hip_sharded_hash* s) {
+// drift_dt != nullptr: the drift of the step runs inside the box pass (x += v dt + a dt^2/2 with a = acc)
+static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = nullptr) {
   const int W = s->W;
   const size_t nstats = (size_t)W * W + kHistCap;
   const bool rccl = s->comm->transport == NBODY_HIP_TRANSPORT_RCCL;
@@ -310,21 +320,29 @@ static int hash_force_phase(nbody_hip_sharded_hash* s) {
   // -- 1: local boxes, global box ----------------------------------------------------------------------------------
   for (auto& x : s->sh) {
     NBH_HIP(hipSetDevice(x.device));
-    if (x.n) {
+    if (x.n && drift_dt) {
+      if (int rc = nbody_hip_drift_bbox_packed(x.ctx, reinterpret_cast<nbody_float4*>(x.posm), reinterpret_cast<nbody_float4*>(x.vel),
+                                               reinterpret_cast<nbody_float4*>(x.acc), x.n, *drift_dt, x.enc, x.box))
+        return rc;
+    } else if (x.n) {
       if (int rc = nbody_hip_bbox_packed(x.ctx, reinterpret_cast<nbody_float4*>(x.posm), x.n, x.box)) return rc;
     } else {
       hipLaunchKernelGGL(box_empty_kernel, dim3(1), dim3(64), 0, x.compute, x.box);
     }
+    if (rccl) hipLaunchKernelGGL(box_flip_kernel, dim3(1), dim3(64), 0, x.compute, x.box);  // {lo, -hi}: ONE min all-reduce
     NBH_HIP(hipEventRecord(x.ev_a, x.compute));
   }
   if (rccl) {
     if (s->sh.size() > 1) NBH_NCCL(api, api->GroupStart());
     for (auto& x : s->sh) {
       NBH_HIP(hipSetDevice(x.device));
-      NBH_NCCL(api, api->AllReduce(x.box, x.gbox, 3, ncclFloat, ncclMin, x.nccl, x.compute));
-      NBH_NCCL(api, api->AllReduce(x.box + 3, x.gbox + 3, 3, ncclFloat, ncclMax, x.nccl, x.compute));
+      NBH_NCCL(api, api->AllReduce(x.box, x.gbox, 6, ncclFloat, ncclMin, x.nccl, x.compute));
     }
     if (s->sh.size() > 1) NBH_NCCL(api, api->GroupEnd());
+    for (auto& x : s->sh) {
+      NBH_HIP(hipSetDevice(x.device));
+      hipLaunchKernelGGL(box_flip_kernel, dim3(1), dim3(64), 0, x.compute, x.gbox);
+    }
   } else {
     PeerPtrs pp;
     pp.n = W;
@@ -376,9 +394,7 @@ static int hash_force_phase(nbody_hip_sharded_hash* s) {
   // -- 4: the host synchronisation ------------------------------------------------------------------------------------
   for (auto& x : s->sh) {
     NBH_HIP(hipSetDevice(x.device));
-    NBH_HIP(hipMemcpyAsync(x.h_box, x.gbox, 6 * sizeof(float), hipMemcpyDeviceToHost, x.compute));
-    NBH_HIP(hipMemcpyAsync(x.h_stats, x.stats_sum, nstats * sizeof(int), hipMemcpyDeviceToHost, x.compute));
-    NBH_HIP(hipMemcpyAsync(x.h_info, x.info, 4 * sizeof(int), hipMemcpyDeviceToHost, x.compute));
+    NBH_HIP(hipMemcpyAsync(x.h_block, x.sum_block, (nstats + 10) * sizeof(int), hipMemcpyDeviceToHost, x.compute));
   }
   for (auto& x : s->sh) {
     NBH_HIP(hipSetDevice(x.device));
@@ -640,13 +656,8 @@ extern "C" int nbody_hip_sharded_hash_step(nbody_hip_sharded_hash* s, float dt, 
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state (call nbody_hip_sharded_hash_set_state first)");
   if (!(dt > 0.0f) || !(dt <= 1.0f)) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Time step must be in range (0, 1]");
   for (int k = 0; k < steps; k++) {
-    for (auto& x : s->sh)
-      if (x.n)
-        if (int rc = nbody_hip_drift_packed(x.ctx, reinterpret_cast<nbody_float4*>(x.posm), reinterpret_cast<nbody_float4*>(x.vel),
-                                            reinterpret_cast<nbody_float4*>(x.acc), x.n, dt))
-          return rc;
-    // acc (= a_old) migrates with the bodies inside the force phase
-    if (int rc = hash_force_phase(s)) return rc;
+    // the drift runs inside the force phase's box pass; acc (= a_old) migrates with the bodies there
+    if (int rc = hash_force_phase(s, &dt)) return rc;
     for (auto& x : s->sh)
       if (x.n)
         if (int rc = nbody_hip_kick_packed(x.ctx, reinterpret_cast<nbody_float4*>(x.vel), reinterpret_cast<nbody_float4*>(x.acc),

@@ -270,8 +270,12 @@ extern "C" int nbody_hip_slab_partition(nbody_hip_ctx* ctx, const nbody_float4* 
   int* layer_of = reinterpret_cast<int*>(ws + off_layer);
   int* block_counts = reinterpret_cast<int*>(ws + off_bc);
   int* totals = reinterpret_cast<int*>(ws + off_gb);
-  NBH_HIP(hipMemsetAsync(send_matrix_dev, 0, (size_t)world * world * sizeof(int), st));
-  NBH_HIP(hipMemsetAsync(hist_dev, 0, (size_t)hist_cap * sizeof(int), st));
+  if (hist_dev == send_matrix_dev + (size_t)world * world) {  // one block (the sharded hosts'): one fill
+    NBH_HIP(hipMemsetAsync(send_matrix_dev, 0, ((size_t)world * world + hist_cap) * sizeof(int), st));
+  } else {
+    NBH_HIP(hipMemsetAsync(send_matrix_dev, 0, (size_t)world * world * sizeof(int), st));
+    NBH_HIP(hipMemsetAsync(hist_dev, 0, (size_t)hist_cap * sizeof(int), st));
+  }
   hipLaunchKernelGGL(slab_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(posm), ni,
                      chunk, gbox_dev, cell_size, world, hist_cap, dest, layer_of, block_counts, hist_dev, info_dev);
   NBH_LAUNCH_CHECK();

@@ -112,6 +112,28 @@ __global__ __launch_bounds__(kBlock) void bbox_kernel(const float4* __restrict__
   block_bbox_commit(lo, hi, red, enc);
 }
 
+// the float4 drift (drift_packed_kernel, integrator.hip: same arithmetic) with the box of the NEW positions in the
+// same pass: the sharded spatial hash's first kernel of a step
+__global__ __launch_bounds__(kBlock) void drift_bbox_packed_kernel(float4* __restrict__ posm, const float4* __restrict__ vel,
+                                                                   const float4* __restrict__ acc, int n, float dt,
+                                                                   unsigned int* __restrict__ enc) {
+  __shared__ float red[4][6];
+  const float dt2_half = 0.5f * dt * dt;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 p = posm[i];
+    const float4 v = vel[i], a = acc[i];
+    p.x = drift1(p.x, v.x, a.x, dt, dt2_half);
+    p.y = drift1(p.y, v.y, a.y, dt, dt2_half);
+    p.z = drift1(p.z, v.z, a.z, dt, dt2_half);
+    posm[i] = p;
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+  block_bbox_commit(lo, hi, red, enc);
+}
+
 // SoA -> float4 packing and the bounding box in ONE pass (the build's first two kernels fused):
 // <= 256 workgroups stride over the bodies, write posm and keep the running min/max
 __global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -749,6 +771,13 @@ __global__ __launch_bounds__(kBlock) void cell_z_kernel(const float4* __restrict
 __global__ void bbox_decode_kernel(const unsigned int* __restrict__ enc, float* __restrict__ out) {
   if (threadIdx.x < 6) out[threadIdx.x] = ordered_to_float(enc[threadIdx.x]);
 }
+// ... leaving the empty box behind for the next pass (enc private to the caller: no bbox_init_kernel per step)
+__global__ void bbox_decode_rearm_kernel(unsigned int* __restrict__ enc, float* __restrict__ out) {
+  if (threadIdx.x < 6) {
+    out[threadIdx.x] = ordered_to_float(enc[threadIdx.x]);
+    enc[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  }
+}
 
 }  // namespace nbh
 
@@ -1159,6 +1188,23 @@ extern "C" int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* pos
   unsigned int* enc = static_cast<unsigned int*>(ctx->reduce.ptr);
   if (int rc = launch_bbox(ctx, reinterpret_cast<const float4*>(posm), (int)n, enc)) return rc;
   hipLaunchKernelGGL(bbox_decode_kernel, dim3(1), dim3(64), 0, ctx->stream, enc, bounds_device);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_drift_bbox_packed(nbody_hip_ctx* ctx, nbody_float4* posm, const nbody_float4* vel,
+                                           const nbody_float4* acc, size_t n, float dt, unsigned int* enc_device,
+                                           float* bounds_device) {
+  if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
+  if (!posm || !vel || !acc || !enc_device || !bounds_device) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (n == 0 || n > 0x3fffffffu) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "body count out of range");
+  NBH_HIP(hipSetDevice(ctx->device));
+  const int blocks = (int)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(drift_bbox_packed_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream,
+                     reinterpret_cast<float4*>(posm), reinterpret_cast<const float4*>(vel),
+                     reinterpret_cast<const float4*>(acc), (int)n, dt, enc_device);
+  NBH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bbox_decode_rearm_kernel, dim3(1), dim3(64), 0, ctx->stream, enc_device, bounds_device);
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }

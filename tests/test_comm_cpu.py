@@ -74,6 +74,10 @@ def test_comm_entry_points_without_a_device(nb):
     assert lib.nbody_hip_sharded_direct_create(None, 10, 1.0, 0.1, C.byref(h)) == nb._lib.ERR_STATE
     assert lib.nbody_hip_sharded_direct_step(None, 0.1, 1) == nb._lib.ERR_STATE
     assert lib.nbody_hip_comm_destroy(None) == 0 and lib.nbody_hip_sharded_direct_destroy(None) == 0
+    assert lib.nbody_hip_sharded_hash_create(None, 10, 1.0, 0.1, 1.0, 1.0, C.byref(h)) == nb._lib.ERR_STATE
+    assert lib.nbody_hip_sharded_hash_step(None, 0.1, 1) == nb._lib.ERR_STATE
+    assert lib.nbody_hip_sharded_hash_forces(None) == nb._lib.ERR_STATE
+    assert lib.nbody_hip_sharded_hash_destroy(None) == 0
     with pytest.raises(nb.ValidationException):
         nb.sharded.shard_bounds(10, 2, 2)
     with pytest.raises(nb.DeviceException):
