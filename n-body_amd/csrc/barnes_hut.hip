@@ -36,11 +36,15 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "onesweep.h"
 
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                              rocprim::default_config, nbh::kSortMergeLimit>;
 #ifndef NBH_BH_RADIX_BITS
 #define NBH_BH_RADIX_BITS 10
+#endif
+#ifndef NBH_BH_OWN_SORT
+#define NBH_BH_OWN_SORT 1   // 0: rocprim::radix_sort_pairs everywhere (A/B builds)
 #endif
 #if NBH_BH_RADIX_BITS > 0
 // 63-bit keys: digits of NBH_BH_RADIX_BITS bits per onesweep pass instead of the default 8 -- 60 key bits at the
@@ -1374,6 +1378,13 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
       e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, static_cast<unsigned int*>(g->d_keys_a),
                                                 static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
                                                 30, g->ctx->stream);
+    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && n > kSortMergeLimit) {  // the Onesweep driver of our own
+      size_t t2 = 0;
+      e = onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
+          nullptr, t2, static_cast<const unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b),
+          g->d_idx_a, g->d_idx_b, n, 0, 63, g->ctx->stream);
+      if (t2 > t1) t1 = t2;
+    }
     g->tmp_bytes = t1;
     if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
   }
@@ -1543,7 +1554,17 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     g->enc_replays = ctx->graph_replays;
     size_t tmp = g->tmp_bytes;
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
-    NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
+    // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (one fill instead of 13, onesweep.h)
+    if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0) {
+      if (NBH_BH_OWN_SORT && n > kSortMergeLimit) {
+        NBH_HIP(onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
+            g->d_tmp, tmp, static_cast<const K*>(ka), kb, g->d_idx_a, g->d_idx_b, n, (unsigned)first_bit, (unsigned)key_bits, st));
+      } else {
+        NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
+      }
+    } else {
+      NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
+    }
     unsigned int* lvlmask = reinterpret_cast<unsigned int*>(g->d_idx_a);  // idx_a is free after the sort
     // the ranks are laid out for THIS build's body count: G groups of 64 over the positions 0 .. ni
     const int G = (ni + 64) / 64;

@@ -1,0 +1,122 @@
+// SPDX-License-Identifier: MIT
+// A host driver of our own around rocPRIM's Onesweep radix-sort DEVICE functions (ROCm 7.x:
+// rocprim/device/detail/device_radix_sort.hpp: onesweep_histograms, onesweep_scan_histograms, onesweep_iteration).
+//
+// Why: rocprim::radix_sort_pairs issues, per digit pass, one hipMemsetAsync for the decoupled-look-back states and one
+// for the ordered block id, plus one for the digit histograms: 13 fill launches around the 8 kernels of a 60-bit sort,
+// each ~5-6 us on the stream (rocprofv3: 15 fills = 93 us of the 0.49 ms Barnes-Hut build at N = 2^20; 5 of the
+// spatial hash's 0.32 ms build).  Here every pass has its OWN look-back states and block-id counter, laid out behind
+// the histograms in one block that ONE fill clears: 13 launches -> 1.  The kernels, their tile shapes (histogram
+// 256 x 12, pass 1024 x 8, `match` ranking) and therefore the sorted output are rocPRIM's.
+//
+// Passes alternate between a temporary pair of arrays and the output so that the last one lands in the output
+// (in -> tmp -> out -> tmp -> ... -> out), as rocPRIM's own driver does.  Stable.  n < 2^30.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <iterator>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace nbh {
+namespace onesweep {
+
+constexpr unsigned kHistBlock = 256, kHistItems = 12;
+constexpr unsigned kPassBlock = 1024, kPassItems = 8;
+using BlockId = rocprim::detail::block_id_wrapper<unsigned int, true>;
+using Lookback = rocprim::detail::onesweep_lookback_state;
+
+template <unsigned RB, class Key>
+__global__ __launch_bounds__(kHistBlock) void hist_kernel(const Key* keys, unsigned int* counts, unsigned int size,
+                                                           unsigned int full_blocks, unsigned int begin_bit,
+                                                           unsigned int end_bit) {
+  rocprim::detail::onesweep_histograms<kHistBlock, kHistItems, RB, false>(keys, counts, size, full_blocks,
+                                                                          rocprim::identity_decomposer{}, begin_bit, end_bit);
+}
+
+template <unsigned RB>
+__global__ __launch_bounds__(kHistBlock) void scan_kernel(unsigned int* counts) {
+  rocprim::detail::onesweep_scan_histograms<kHistBlock, RB>(counts);
+}
+
+template <unsigned RB, class KI, class KO, class VI, class VO>
+__global__ __launch_bounds__(kPassBlock) void pass_kernel(KI keys_in, KO keys_out, VI vals_in, VO vals_out,
+                                                           unsigned int size, unsigned int* offs_in,
+                                                           unsigned int* offs_out, Lookback* lookback, unsigned int bit,
+                                                           unsigned int cur_bits, unsigned int full_blocks, BlockId bid) {
+  rocprim::detail::onesweep_iteration<kPassBlock, kPassItems, RB, false, rocprim::block_radix_rank_algorithm::match>(
+      keys_in, keys_out, vals_in, vals_out, size, offs_in, offs_out, lookback, rocprim::identity_decomposer{}, bit,
+      cur_bits, full_blocks, bid);
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// tmp == nullptr: size query.  keys_in may not alias the temporary arrays; vals_in / vals_out may be any iterators
+// whose value type is VT (the temporary value array holds VT).
+template <unsigned RB, class Key, class VI, class VO>
+hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* keys_out, VI vals_in, VO vals_out, size_t n,
+                      unsigned int begin_bit, unsigned int end_bit, hipStream_t st) {
+  using VT = typename std::iterator_traits<VI>::value_type;
+  constexpr unsigned int R = 1u << RB;
+  if (n >= (1u << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
+  const unsigned int size = (unsigned int)n;
+  const unsigned int places = (end_bit - begin_bit + RB - 1) / RB;
+  const unsigned int pass_items = kPassBlock * kPassItems, hist_items = kHistBlock * kHistItems;
+  const unsigned int blocks = (size + pass_items - 1) / pass_items;
+  const unsigned int hblocks = (size + hist_items - 1) / hist_items;
+  // [ counts: places x R | carry: R | block ids: places | look-back: places x blocks x R ]  <- one fill
+  const size_t words = (size_t)places * R + R + places + (size_t)places * blocks * R;
+  const size_t off_keys = align_up(words * sizeof(unsigned int));
+  const size_t off_vals = off_keys + align_up(n * sizeof(Key));
+  const size_t total = off_vals + align_up(n * sizeof(VT));
+  if (!tmp) {
+    tmp_bytes = total;
+    return hipSuccess;
+  }
+  if (tmp_bytes < total) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  char* base = static_cast<char*>(tmp);
+  unsigned int* counts = reinterpret_cast<unsigned int*>(base);
+  unsigned int* carry = counts + (size_t)places * R;
+  unsigned int* ids = carry + R;
+  Lookback* lookback = reinterpret_cast<Lookback*>(ids + places);
+  Key* keys_tmp = reinterpret_cast<Key*>(base + off_keys);
+  VT* vals_tmp = reinterpret_cast<VT*>(base + off_vals);
+  hipError_t e = hipMemsetAsync(base, 0, words * sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((hist_kernel<RB, Key>), dim3(hblocks), dim3(kHistBlock), 0, st, keys_in, counts, size,
+                     size % hist_items == 0 ? hblocks : hblocks - 1, begin_bit, end_bit);
+  hipLaunchKernelGGL((scan_kernel<RB>), dim3(places), dim3(kHistBlock), 0, st, counts);
+  const unsigned int full_blocks = size % pass_items == 0 ? blocks : blocks - 1;
+  bool to_output = (places - 1) % 2 == 0;
+  bool from_input = true;
+  unsigned int bit = begin_bit;
+  for (unsigned int place = 0; place < places; place++, bit += RB) {
+    const unsigned int cur = end_bit - bit < RB ? end_bit - bit : RB;
+    unsigned int* offs = counts + (size_t)place * R;
+    Lookback* lb = lookback + (size_t)place * blocks * R;
+    BlockId bid = BlockId::create(ids + place);
+    if (from_input && to_output) {
+      hipLaunchKernelGGL((pass_kernel<RB, const Key*, Key*, VI, VO>), dim3(blocks), dim3(kPassBlock), 0, st, keys_in,
+                         keys_out, vals_in, vals_out, size, offs, carry, lb, bit, cur, full_blocks, bid);
+    } else if (from_input) {
+      hipLaunchKernelGGL((pass_kernel<RB, const Key*, Key*, VI, VT*>), dim3(blocks), dim3(kPassBlock), 0, st, keys_in,
+                         keys_tmp, vals_in, vals_tmp, size, offs, carry, lb, bit, cur, full_blocks, bid);
+    } else if (to_output) {
+      hipLaunchKernelGGL((pass_kernel<RB, const Key*, Key*, const VT*, VO>), dim3(blocks), dim3(kPassBlock), 0, st,
+                         static_cast<const Key*>(keys_tmp), keys_out, static_cast<const VT*>(vals_tmp), vals_out, size,
+                         offs, carry, lb, bit, cur, full_blocks, bid);
+    } else {  // out -> tmp: the output arrays are read back, so they must be readable through their iterators
+      hipLaunchKernelGGL((pass_kernel<RB, const Key*, Key*, VO, VT*>), dim3(blocks), dim3(kPassBlock), 0, st,
+                         static_cast<const Key*>(keys_out), keys_tmp, vals_out, vals_tmp, size, offs, carry, lb, bit, cur,
+                         full_blocks, bid);
+    }
+    from_input = false;
+    to_output = !to_output;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace onesweep
+}  // namespace nbh

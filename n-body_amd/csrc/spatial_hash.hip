@@ -33,6 +33,7 @@
 #include <rocprim/iterator/zip_iterator.hpp>
 
 #include "common.h"
+#include "onesweep.h"
 
 // Binning = ONE stable sort by cell id that carries the bodies along: the values are (float4 body, original
 // index) pairs -- a zip of the packed bodies with a counting iterator on the way in, of the cell-ordered body array
@@ -41,6 +42,9 @@
 // passes instead of three.
 #ifndef NBH_HASH_RADIX_BITS
 #define NBH_HASH_RADIX_BITS 10
+#endif
+#ifndef NBH_HASH_OWN_SORT
+#define NBH_HASH_OWN_SORT 1   // 0: rocprim::radix_sort_pairs everywhere (A/B builds)
 #endif
 using SortConfig = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
@@ -789,6 +793,21 @@ static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned i
                                       hipStream_t st) {
   auto vin = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_in, rocprim::make_counting_iterator<int>(0)));
   auto vout = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_out, idx_out));
+#if NBH_HASH_OWN_SORT
+  // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (one fill instead of five, onesweep.h)
+  if (!temp) {  // size query: room for either path
+    size_t a = 0, b = 0;
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, a, keys_in, keys_out, vin, vout, n, 0, bits, st);
+    if (e != hipSuccess) return e;
+    e = nbh::onesweep::sort_pairs<NBH_HASH_RADIX_BITS>(nullptr, b, static_cast<const unsigned int*>(keys_in), keys_out, vin, vout,
+                                                       n, 0u, (unsigned)bits, st);
+    temp_bytes = a > b ? a : b;
+    return e;
+  }
+  if (n > nbh::kSortMergeLimit)
+    return nbh::onesweep::sort_pairs<NBH_HASH_RADIX_BITS>(temp, temp_bytes, static_cast<const unsigned int*>(keys_in), keys_out,
+                                                          vin, vout, n, 0u, (unsigned)bits, st);
+#endif
   return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vin, vout, n, 0, bits, st);
 }
 
