@@ -2,11 +2,21 @@
 // C ABI declared in include/nbody_hip.h.
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
 
 namespace nbh {
+
+size_t own_sort_from(size_t compiled_default) {
+  if (const char* e = std::getenv("NBH_OWN_SORT_FROM")) {
+    char* end = nullptr;
+    const long long v = std::strtoll(e, &end, 10);
+    if (end != e && v >= 0) return (size_t)v;
+  }
+  return compiled_default;
+}
 
 static thread_local char g_err[512] = "";
 

@@ -152,8 +152,14 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict
                                                         const unsigned int* __restrict__ enc,
                                                         unsigned int* __restrict__ enc_next,
                                                         TreeRoot* __restrict__ root_out, int* __restrict__ level_base,
-                                                        K* __restrict__ keys, int* __restrict__ idx) {
+                                                        K* __restrict__ keys, int* __restrict__ idx,
+                                                        unsigned int* __restrict__ zero_a, unsigned int words_a,
+                                                        unsigned int* __restrict__ zero_b, unsigned int words_b) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  // what the next kernels want zeroed (the sort's histograms / look-back states, the odd-group marker planes):
+  // ~1.4 words per thread here instead of four fill launches on the stream
+  for (unsigned int w = i; w < words_a; w += gridDim.x * kBlock) zero_a[w] = 0u;
+  for (unsigned int w = i; w < words_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
   const TreeRoot root = root_from_bbox(enc);
   if (i == 0) {
     *root_out = root;
@@ -1301,6 +1307,7 @@ struct nbody_hip_tree {
   dd4* d_prefix = nullptr;  // prefix_cap prefix sums of the sorted bodies + workgroup totals + offsets
   size_t prefix_cap = 0;
   int tune_replicas = 0, tune_split_level = 0;  // 0 = automatic
+  size_t own_sort_from = kOwnSortFromTree;     // onesweep.h driver from this many bodies (63-bit keys)
   int tune_form = 0;                            // walk without replicas: 0 = automatic, 1 = plain, 2 = pair walk
   // cost-ordered schedule of the pair walk (walk_plan_kernel): node visits per wave of the previous walk
   int* d_cost = nullptr;         // waves
@@ -1378,7 +1385,8 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
       e = rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, static_cast<unsigned int*>(g->d_keys_a),
                                                 static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
                                                 30, g->ctx->stream);
-    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && n > kSortMergeLimit) {  // the Onesweep driver of our own
+    g->own_sort_from = own_sort_from(kOwnSortFromTree);
+    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && n >= g->own_sort_from) {  // the Onesweep driver of our own
       size_t t2 = 0;
       e = onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
           nullptr, t2, static_cast<const unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b),
@@ -1547,18 +1555,33 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   bool prefix_forked = false;
   auto topology = [&](auto* ka, auto* kb, int first_bit, int key_bits) -> int {
     using K = std::remove_pointer_t<decltype(ka)>;
+    // the ranks are laid out for THIS build's body count: G groups of 64 over the positions 0 .. ni
+    const int G = (ni + 64) / 64;
+    const size_t tbl = (size_t)levels * (size_t)G;
+    unsigned long long* odd_plane = g->d_plane + tbl;
+    // even-aligned sibling groups are what the pair walk needs: trees it will walk (from kPairFrom bodies, or when that
+    // walk form is forced) get them, smaller trees keep plain ids and save three launches
+    g->aligned = ni >= kPairFrom || g->tune_form == 2;
+    bool own_sort = false;
+    size_t sort_words = 0;
+    if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0) {
+      own_sort = NBH_BH_OWN_SORT && n >= g->own_sort_from;
+      if (own_sort) sort_words = onesweep::clear_words<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(n, (unsigned)first_bit, (unsigned)key_bits);
+    }
     hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, enc, enc_next, g->d_root,
-                       g->d_level_base, ka, g->d_idx_a);
+                       g->d_level_base, ka, g->d_idx_a, static_cast<unsigned int*>(g->d_tmp), (unsigned int)sort_words,
+                       reinterpret_cast<unsigned int*>(odd_plane), g->aligned ? (unsigned int)(2 * tbl) : 0u);
     NBH_LAUNCH_CHECK();
     g->enc_armed = !ctx->capturing;
     g->enc_replays = ctx->graph_replays;
     size_t tmp = g->tmp_bytes;
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
-    // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (one fill instead of 13, onesweep.h)
+    // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (no fill launches, onesweep.h)
     if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0) {
-      if (NBH_BH_OWN_SORT && n > kSortMergeLimit) {
+      if (own_sort) {
         NBH_HIP(onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
-            g->d_tmp, tmp, static_cast<const K*>(ka), kb, g->d_idx_a, g->d_idx_b, n, (unsigned)first_bit, (unsigned)key_bits, st));
+            g->d_tmp, tmp, static_cast<const K*>(ka), kb, g->d_idx_a, g->d_idx_b, n, (unsigned)first_bit, (unsigned)key_bits, st,
+            /*cleared=*/true));
       } else {
         NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
       }
@@ -1566,16 +1589,8 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
       NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
     }
     unsigned int* lvlmask = reinterpret_cast<unsigned int*>(g->d_idx_a);  // idx_a is free after the sort
-    // the ranks are laid out for THIS build's body count: G groups of 64 over the positions 0 .. ni
-    const int G = (ni + 64) / 64;
-    const size_t tbl = (size_t)levels * (size_t)G;
-    unsigned long long* odd_plane = g->d_plane + tbl;
     int* odd_off = g->d_rank_off + tbl;
     int* odd_totals = g->d_totals + (kMaxDepth + 3);
-    // even-aligned sibling groups are what the pair walk needs: trees it will walk (from kPairFrom bodies, or when that
-    // walk form is forced) get them, smaller trees keep plain ids and save three launches
-    g->aligned = ni >= kPairFrom || g->tune_form == 2;
-    if (g->aligned) NBH_HIP(hipMemsetAsync(odd_plane, 0, tbl * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, kb, ni,
                        g->max_depth, g->leaf_max, lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, G);
     if (fused && side_ok) {

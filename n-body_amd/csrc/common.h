@@ -24,6 +24,13 @@ constexpr int kNumCU = 256;   // MI355X
 // to Onesweep above `merge_sort_limit` (default 2^20, i.e. exactly NOT at the BASELINE size); measured:
 // merge sort wins at 262,144 keys (0.24 vs 0.26 ms tree build), Onesweep from 524,288 (0.14 vs 0.18 ms)
 constexpr size_t kSortMergeLimit = NBH_SORT_MERGE_LIMIT;
+// ... and our own driver of the Onesweep kernels (onesweep.h: no fill launches) takes over from kOwnSortFromTree
+// bodies in the Barnes-Hut build (63-bit keys, index payload) and kOwnSortFromGrid in the spatial hash (32-bit keys,
+// float4 + index payload, where the merge sort is dearer) -- profiles/r03_sort_crossover.txt.  NBH_OWN_SORT_FROM in
+// the environment overrides both when a tree / grid is created (the hook tools/sort_crossover.py measures with, not
+// an interface).
+constexpr size_t kOwnSortFromTree = 250000, kOwnSortFromGrid = 120000;
+size_t own_sort_from(size_t compiled_default);
 
 #ifdef __HIPCC__
 // x + v dt + a (dt^2 / 2) as p + fma(a, h, v * dt): the contraction nvcc's default -fmad makes of

@@ -52,11 +52,22 @@ __global__ __launch_bounds__(kPassBlock) void pass_kernel(KI keys_in, KO keys_ou
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// 32-bit words at the front of the temporary storage that must be ZERO when the sort starts (digit histograms,
+// carry, block ids, look-back states of every pass): sort_pairs clears them itself unless the caller says it already
+// has (`cleared`: e.g. inside the kernel that writes the keys -- one launch less)
+template <unsigned RB>
+inline size_t clear_words(size_t n, unsigned int begin_bit, unsigned int end_bit) {
+  constexpr unsigned int R = 1u << RB;
+  const size_t places = (end_bit - begin_bit + RB - 1) / RB;
+  const size_t blocks = (n + (size_t)kPassBlock * kPassItems - 1) / ((size_t)kPassBlock * kPassItems);
+  return places * R + R + places + places * blocks * R;
+}
+
 // tmp == nullptr: size query.  keys_in may not alias the temporary arrays; vals_in / vals_out may be any iterators
 // whose value type is VT (the temporary value array holds VT).
 template <unsigned RB, class Key, class VI, class VO>
 hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* keys_out, VI vals_in, VO vals_out, size_t n,
-                      unsigned int begin_bit, unsigned int end_bit, hipStream_t st) {
+                      unsigned int begin_bit, unsigned int end_bit, hipStream_t st, bool cleared = false) {
   using VT = typename std::iterator_traits<VI>::value_type;
   constexpr unsigned int R = 1u << RB;
   if (n >= (1u << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
@@ -66,7 +77,7 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* key
   const unsigned int blocks = (size + pass_items - 1) / pass_items;
   const unsigned int hblocks = (size + hist_items - 1) / hist_items;
   // [ counts: places x R | carry: R | block ids: places | look-back: places x blocks x R ]  <- one fill
-  const size_t words = (size_t)places * R + R + places + (size_t)places * blocks * R;
+  const size_t words = clear_words<RB>(n, begin_bit, end_bit);
   const size_t off_keys = align_up(words * sizeof(unsigned int));
   const size_t off_vals = off_keys + align_up(n * sizeof(Key));
   const size_t total = off_vals + align_up(n * sizeof(VT));
@@ -83,8 +94,10 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* key
   Lookback* lookback = reinterpret_cast<Lookback*>(ids + places);
   Key* keys_tmp = reinterpret_cast<Key*>(base + off_keys);
   VT* vals_tmp = reinterpret_cast<VT*>(base + off_vals);
-  hipError_t e = hipMemsetAsync(base, 0, words * sizeof(unsigned int), st);
-  if (e != hipSuccess) return e;
+  if (!cleared) {
+    hipError_t e = hipMemsetAsync(base, 0, words * sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL((hist_kernel<RB, Key>), dim3(hblocks), dim3(kHistBlock), 0, st, keys_in, counts, size,
                      size % hist_items == 0 ? hblocks : hblocks - 1, begin_bit, end_bit);
   hipLaunchKernelGGL((scan_kernel<RB>), dim3(places), dim3(kHistBlock), 0, st, counts);

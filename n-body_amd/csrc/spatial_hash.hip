@@ -283,8 +283,11 @@ __device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim
 __global__ __launch_bounds__(kBlock) void assign_cells_kernel(const float4* __restrict__ posm, int n,
                                                               const GridInfo* __restrict__ info,
                                                               float cell,
-                                                              unsigned int* __restrict__ keys) {
+                                                              unsigned int* __restrict__ keys,
+                                                              unsigned int* __restrict__ zero, unsigned int zero_words) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  // what the sort wants zeroed (onesweep.h: histograms, look-back states): here instead of a fill launch
+  for (unsigned int w = i; w < zero_words; w += gridDim.x * kBlock) zero[w] = 0u;
   if (i >= n) return;
   const float4 p = posm[i];
   const int gx = info->dims[0], gy = info->dims[1], gz = info->dims[2];
@@ -790,7 +793,7 @@ using namespace nbh;
 // stable radix sort of the cell ids carrying (body, original index) along; temp == nullptr: size query
 static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned int* keys_in, unsigned int* keys_out,
                                       const float4* bodies_in, float4* bodies_out, int* idx_out, size_t n, int bits,
-                                      hipStream_t st) {
+                                      hipStream_t st, size_t own_from = nbh::kOwnSortFromGrid, bool cleared = false) {
   auto vin = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_in, rocprim::make_counting_iterator<int>(0)));
   auto vout = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_out, idx_out));
 #if NBH_HASH_OWN_SORT
@@ -804,9 +807,9 @@ static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned i
     temp_bytes = a > b ? a : b;
     return e;
   }
-  if (n > nbh::kSortMergeLimit)
+  if (n >= own_from)
     return nbh::onesweep::sort_pairs<NBH_HASH_RADIX_BITS>(temp, temp_bytes, static_cast<const unsigned int*>(keys_in), keys_out,
-                                                          vin, vout, n, 0u, (unsigned)bits, st);
+                                                          vin, vout, n, 0u, (unsigned)bits, st, cleared);
 #endif
   return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vin, vout, n, 0, bits, st);
 }
@@ -825,6 +828,7 @@ struct nbody_hip_grid {
   float4* d_sorted = nullptr;
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  size_t own_sort_from = nbh::kOwnSortFromGrid;  // onesweep.h driver from this many bodies
   int *d_cell_start = nullptr, *d_cell_end = nullptr;  // lazily sized (inspection API only)
   long long cell_capacity = 0;
   int* d_cell_lb = nullptr;            // first sorted position of every cell (+ 1 entry); dense grids only
@@ -862,6 +866,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   nbody_hip_grid* g = new nbody_hip_grid();
   g->ctx = ctx;
   g->max_particles = max_particles;
+  g->own_sort_from = nbh::own_sort_from(nbh::kOwnSortFromGrid);
   g->cell_size = cell_size;
   const size_t n = max_particles;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_enc), 8 * sizeof(unsigned int));
@@ -967,13 +972,16 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     if (g->info.total > 100000000LL)  // :252-254
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   }
+  const int sort_bits = bits_for(g->info.total);
+  const bool own_sort = NBH_HASH_OWN_SORT && n >= g->own_sort_from;
+  const size_t zero_words = own_sort ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)sort_bits) : 0;
   hipLaunchKernelGGL(assign_cells_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_info,
-                     g->cell_size, g->d_keys_a);
+                     g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words);
   NBH_LAUNCH_CHECK();
   size_t tmp = g->sort_tmp_bytes;
   // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
   NBH_HIP(sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n,
-                              bits_for(g->info.total), st));
+                              sort_bits, st, own_sort ? (size_t)0 : ~(size_t)0, /*cleared=*/own_sort));
   g->lb_valid = false;
   {
     // cells the per-cell start array covers: the whole grid, or the z layers of this rank's slab
