@@ -147,35 +147,56 @@ template <> struct KeyTraits<unsigned long long> {
 // Keys of all bodies; every thread derives the root cube from the bounding box itself (six scalar loads), thread
 // 0 publishes it for the later passes and re-arms the OTHER bounding-box buffer for the next build (two buffers
 // alternate, so the build needs no separate init and no separate root launch).
+// The kernel that has every key in a register also does the sort's bookkeeping (onesweep.h): it zeroes the look-back
+// block of the passes and the odd-group marker planes (zero_a, zero_b: four fill launches less) and, with
+// hist_places > 0, accumulates the digit histograms of the sort in LDS (rocPRIM's histogram kernel, 22 us at N = 2^20,
+// is skipped then); the OTHER histogram buffer is zeroed for the next build.  A fixed grid strides over the bodies.
+constexpr int kTreeHistPlaces = (63 + (NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8) - 1) / (NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8);
+constexpr int kTreeHistWords = kTreeHistPlaces << (NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8);
+constexpr int kTreeHistCopies = onesweep::DigitHistogram<(NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8)>::kCopies;
 template <class K>
-__global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ posm, int n,
+__global__ __launch_bounds__(NBH_HIST_THREADS) void morton_kernel(const float4* __restrict__ posm, int n,
                                                         const unsigned int* __restrict__ enc,
                                                         unsigned int* __restrict__ enc_next,
                                                         TreeRoot* __restrict__ root_out, int* __restrict__ level_base,
                                                         K* __restrict__ keys, int* __restrict__ idx,
                                                         unsigned int* __restrict__ zero_a, unsigned int words_a,
-                                                        unsigned int* __restrict__ zero_b, unsigned int words_b) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  // what the next kernels want zeroed (the sort's histograms / look-back states, the odd-group marker planes):
-  // ~1.4 words per thread here instead of four fill launches on the stream
-  for (unsigned int w = i; w < words_a; w += gridDim.x * kBlock) zero_a[w] = 0u;
-  for (unsigned int w = i; w < words_b; w += gridDim.x * kBlock) zero_b[w] = 0u;
+                                                        unsigned int* __restrict__ zero_b, unsigned int words_b,
+                                                        unsigned int* __restrict__ hist, unsigned int* __restrict__ hist_next,
+                                                        int hist_places, int first_bit) {
+  using Hist = onesweep::DigitHistogram<(NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8)>;
+  __shared__ unsigned int h[kTreeHistWords];
+  const int t0 = blockIdx.x * NBH_HIST_THREADS + threadIdx.x, stride = gridDim.x * NBH_HIST_THREADS;
+  for (unsigned int w = t0; w < words_a; w += stride) zero_a[w] = 0u;
+  for (unsigned int w = t0; w < words_b; w += stride) zero_b[w] = 0u;
+  for (int w = t0; w < kTreeHistWords * Hist::kCopies; w += stride) hist_next[w] = 0u;
+  if (hist_places) {
+    Hist::zero(h, hist_places, threadIdx.x, NBH_HIST_THREADS);
+    __syncthreads();
+  }
   const TreeRoot root = root_from_bbox(enc);
-  if (i == 0) {
+  if (t0 == 0) {
     *root_out = root;
     level_base[0] = 0;
     for (int a = 0; a < 3; a++) { enc_next[a] = 0xffffffffu; enc_next[3 + a] = 0u; }  // the empty box
   }
-  if (i >= n) return;
-  const float4 p = posm[i];
   const float s = root.scale * KeyTraits<K>::kRefine;
   const int top = (1 << KeyTraits<K>::kAxisBits) - 1;
-  int qx = (int)((p.x - root.lo[0]) * s);
-  int qy = (int)((p.y - root.lo[1]) * s);
-  int qz = (int)((p.z - root.lo[2]) * s);
-  qx = min(max(qx, 0), top); qy = min(max(qy, 0), top); qz = min(max(qz, 0), top);
-  keys[i] = KeyTraits<K>::interleave(qx, qy, qz);
-  idx[i] = i;
+  for (int i = t0; i < n; i += stride) {
+    const float4 p = posm[i];
+    int qx = (int)((p.x - root.lo[0]) * s);
+    int qy = (int)((p.y - root.lo[1]) * s);
+    int qz = (int)((p.z - root.lo[2]) * s);
+    qx = min(max(qx, 0), top); qy = min(max(qy, 0), top); qz = min(max(qz, 0), top);
+    const K key = KeyTraits<K>::interleave(qx, qy, qz);
+    keys[i] = key;
+    idx[i] = i;
+    if (hist_places) Hist::add(h, key >> first_bit, hist_places);
+  }
+  if (hist_places) {
+    __syncthreads();
+    Hist::flush(h, hist_places, threadIdx.x, NBH_HIST_THREADS, hist, kTreeHistWords);
+  }
 }
 
 
@@ -1282,6 +1303,7 @@ struct nbody_hip_tree {
   int leaf_max = 1;
   int capacity = 0;
   unsigned int* d_enc = nullptr;  // two bounding-box buffers of 8 words (see morton_kernel)
+  unsigned int* d_hist = nullptr; // two digit-count buffers of the sort (kTreeHistWords each), alternating like d_enc
   unsigned int enc_flip = 0;
   bool enc_armed = false;
   unsigned long long enc_replays = 0;
@@ -1330,7 +1352,7 @@ struct nbody_hip_tree {
 
 static void tree_release(nbody_hip_tree* g) {
   if (!g) return;
-  void* ptrs[] = {g->d_enc, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
+  void* ptrs[] = {g->d_enc, g->d_hist, g->d_root, g->d_level_base, g->d_keys_a, g->d_keys_b, g->d_idx_a,
                   g->d_idx_b, g->d_sorted, g->d_plane, g->d_rank_off, g->d_totals, g->d_level_real, g->d_last_tmp,
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
@@ -1427,6 +1449,7 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   g->max_particles = max_particles;
   const size_t n = max_particles;
   hipError_t e = dmalloc(&g->d_enc, 16);
+  if (e == hipSuccess) e = dmalloc(&g->d_hist, 2 * kTreeHistCopies * kTreeHistWords);
   if (e == hipSuccess) e = dmalloc(&g->d_root, 1);
   if (e == hipSuccess) e = dmalloc(&g->d_level_base, kMaxDepth + 3);
   if (e == hipSuccess) e = dmalloc(&g->d_totals, 2 * (kMaxDepth + 3));
@@ -1518,6 +1541,8 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   // two bounding-box buffers alternate: this build's was re-armed by the previous build's morton_kernel
   unsigned int* enc = g->d_enc + 8 * (g->enc_flip & 1);
   unsigned int* enc_next = g->d_enc + 8 * ((g->enc_flip + 1) & 1);
+  unsigned int* hist = g->d_hist + kTreeHistCopies * kTreeHistWords * (g->enc_flip & 1);          // (zeroed by the previous build's
+  unsigned int* hist_next = g->d_hist + kTreeHistCopies * kTreeHistWords * ((g->enc_flip + 1) & 1);  //  morton_kernel, like the box)
   g->enc_flip++;
   // armed: false on the first build and after a build that failed half way.  A recorded step graph replays this
   // very launch sequence on the SAME buffer every time, so while capturing (and right after) the init stays in.
@@ -1568,9 +1593,14 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
       own_sort = NBH_BH_OWN_SORT && n >= g->own_sort_from;
       if (own_sort) sort_words = onesweep::clear_words<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(n, (unsigned)first_bit, (unsigned)key_bits);
     }
-    hipLaunchKernelGGL(morton_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, posm, ni, enc, enc_next, g->d_root,
-                       g->d_level_base, ka, g->d_idx_a, static_cast<unsigned int*>(g->d_tmp), (unsigned int)sort_words,
-                       reinterpret_cast<unsigned int*>(odd_plane), g->aligned ? (unsigned int)(2 * tbl) : 0u);
+    int hist_places = 0;
+    if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0)
+      if (own_sort) hist_places = (key_bits - first_bit + NBH_BH_RADIX_BITS - 1) / NBH_BH_RADIX_BITS;
+    if (hist_places && !armed) NBH_HIP(hipMemsetAsync(hist, 0, kTreeHistCopies * kTreeHistWords * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(morton_kernel<K>, dim3(std::min((ni + NBH_HIST_THREADS - 1) / NBH_HIST_THREADS, NBH_HIST_BLOCKS)), dim3(NBH_HIST_THREADS), 0, st, posm, ni, enc, enc_next,
+                       g->d_root, g->d_level_base, ka, g->d_idx_a, static_cast<unsigned int*>(g->d_tmp),
+                       (unsigned int)sort_words, reinterpret_cast<unsigned int*>(odd_plane),
+                       g->aligned ? (unsigned int)(2 * tbl) : 0u, hist, hist_next, hist_places, first_bit);
     NBH_LAUNCH_CHECK();
     g->enc_armed = !ctx->capturing;
     g->enc_replays = ctx->graph_replays;
@@ -1581,7 +1611,7 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
       if (own_sort) {
         NBH_HIP(onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
             g->d_tmp, tmp, static_cast<const K*>(ka), kb, g->d_idx_a, g->d_idx_b, n, (unsigned)first_bit, (unsigned)key_bits, st,
-            /*cleared=*/true));
+            /*cleared=*/true, hist_places ? hist : nullptr, kTreeHistCopies, kTreeHistWords));
       } else {
         NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
       }

@@ -29,6 +29,13 @@ constexpr size_t kSortMergeLimit = NBH_SORT_MERGE_LIMIT;
 // float4 + index payload, where the merge sort is dearer) -- profiles/r03_sort_crossover.txt.  NBH_OWN_SORT_FROM in
 // the environment overrides both when a tree / grid is created (the hook tools/sort_crossover.py measures with, not
 // an interface).
+// workgroups of the key kernels that also histogram the digits (each flushes its non-empty bins with global atomics)
+#ifndef NBH_HIST_BLOCKS
+#define NBH_HIST_BLOCKS 256
+#endif
+#ifndef NBH_HIST_THREADS
+#define NBH_HIST_THREADS 1024
+#endif
 constexpr size_t kOwnSortFromTree = 250000, kOwnSortFromGrid = 120000;
 size_t own_sort_from(size_t compiled_default);
 

@@ -11,6 +11,9 @@
 //
 // Passes alternate between a temporary pair of arrays and the output so that the last one lands in the output
 // (in -> tmp -> out -> tmp -> ... -> out), as rocPRIM's own driver does.  Stable.  n < 2^30.
+//
+// Two more launches go when the caller helps: `cleared` (it zeroed the look-back block itself, e.g. in the kernel that
+// writes the keys) and `hist` (it accumulated the digit histograms there too: DigitHistogram below).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -35,8 +38,34 @@ __global__ __launch_bounds__(kHistBlock) void hist_kernel(const Key* keys, unsig
                                                                           rocprim::identity_decomposer{}, begin_bit, end_bit);
 }
 
+// copies > 1: the caller accumulated the counts in `copies` replicas `copy_stride` words apart (DigitHistogram::flush
+// spreads the workgroups over them: global atomics on ONE word serialise, 512 workgroups on one bin are a 15 us chain);
+// they are folded into replica 0 first
 template <unsigned RB>
-__global__ __launch_bounds__(kHistBlock) void scan_kernel(unsigned int* counts) {
+__global__ __launch_bounds__(kHistBlock) void scan_kernel(unsigned int* counts, int copies, unsigned int copy_stride) {
+  if (copies > 1) {
+    constexpr unsigned int R = 1u << RB;
+    unsigned int* mine = counts + blockIdx.x * R;
+    constexpr int kPer = (R + kHistBlock - 1) / kHistBlock, kMaxCopies = 8;
+    unsigned int v[kPer][kMaxCopies];  // every load in flight before the first add
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+#pragma unroll
+      for (int c = 0; c < kMaxCopies; c++) {
+        const unsigned int d = threadIdx.x + k * kHistBlock;
+        v[k][c] = (c < copies && d < R) ? mine[(size_t)c * copy_stride + d] : 0u;
+      }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      unsigned int sum = 0;
+#pragma unroll
+      for (int c = 0; c < kMaxCopies; c++) sum += v[k][c];
+      const unsigned int d = threadIdx.x + k * kHistBlock;
+      if (d < R) mine[d] = sum;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   rocprim::detail::onesweep_scan_histograms<kHistBlock, RB>(counts);
 }
 
@@ -49,6 +78,32 @@ __global__ __launch_bounds__(kPassBlock) void pass_kernel(KI keys_in, KO keys_ou
       keys_in, keys_out, vals_in, vals_out, size, offs_in, offs_out, lookback, rocprim::identity_decomposer{}, bit,
       cur_bits, full_blocks, bid);
 }
+
+// Digit histograms of up to PLACES digit places in LDS, for a kernel that has the keys in registers anyway.
+//   __shared__ unsigned int h[PLACES << RB];  zero(h); __syncthreads(); ... add(h, key >> begin_bit, places) per key ...
+//   __syncthreads(); flush(h, places, ..., global_counts, copy_stride)   -- only the bins that are not empty
+template <unsigned RB>
+struct DigitHistogram {
+  static constexpr unsigned int R = 1u << RB;
+  template <class Key>
+  static __device__ __forceinline__ void add(unsigned int* h, Key shifted_key, int places) {
+    for (int p = 0; p < places; p++) {
+      atomicAdd(&h[p * R + (unsigned int)(shifted_key & (Key)(R - 1))], 1u);
+      shifted_key >>= RB;
+    }
+  }
+  static __device__ __forceinline__ void zero(unsigned int* h, int places, int tid, int nthreads) {
+    for (int t = tid; t < places * (int)R; t += nthreads) h[t] = 0u;
+  }
+  // global_counts: kCopies replicas copy_stride words apart; workgroup b adds to replica b % kCopies
+  static constexpr int kCopies = 8;  // (scan_kernel folds at most 8)
+  static __device__ __forceinline__ void flush(const unsigned int* h, int places, int tid, int nthreads,
+                                               unsigned int* __restrict__ global_counts, unsigned int copy_stride) {
+    unsigned int* dst = global_counts + (size_t)(blockIdx.x % kCopies) * copy_stride;
+    for (int t = tid; t < places * (int)R; t += nthreads)
+      if (h[t]) atomicAdd(&dst[t], h[t]);
+  }
+};
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -67,7 +122,8 @@ inline size_t clear_words(size_t n, unsigned int begin_bit, unsigned int end_bit
 // whose value type is VT (the temporary value array holds VT).
 template <unsigned RB, class Key, class VI, class VO>
 hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* keys_out, VI vals_in, VO vals_out, size_t n,
-                      unsigned int begin_bit, unsigned int end_bit, hipStream_t st, bool cleared = false) {
+                      unsigned int begin_bit, unsigned int end_bit, hipStream_t st, bool cleared = false,
+                      unsigned int* hist = nullptr, int hist_copies = 1, unsigned int hist_copy_stride = 0) {
   using VT = typename std::iterator_traits<VI>::value_type;
   constexpr unsigned int R = 1u << RB;
   if (n >= (1u << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
@@ -88,7 +144,7 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* key
   if (tmp_bytes < total) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   char* base = static_cast<char*>(tmp);
-  unsigned int* counts = reinterpret_cast<unsigned int*>(base);
+  unsigned int* counts = reinterpret_cast<unsigned int*>(base);  // (left unused when the caller brings the histograms)
   unsigned int* carry = counts + (size_t)places * R;
   unsigned int* ids = carry + R;
   Lookback* lookback = reinterpret_cast<Lookback*>(ids + places);
@@ -98,9 +154,17 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* key
     hipError_t e = hipMemsetAsync(base, 0, words * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((hist_kernel<RB, Key>), dim3(hblocks), dim3(kHistBlock), 0, st, keys_in, counts, size,
-                     size % hist_items == 0 ? hblocks : hblocks - 1, begin_bit, end_bit);
-  hipLaunchKernelGGL((scan_kernel<RB>), dim3(places), dim3(kHistBlock), 0, st, counts);
+  // hist: places x R digit counts the caller accumulated while it wrote the keys (count of digit d of place p at
+  // [p * R + d], digit = (key >> (begin_bit + p * RB)) & (R - 1)): rocPRIM's histogram kernel flushes every bin of
+  // every 3,072-key tile with a global atomic (2.8 M atomics = 43 us at 4.2 M 32-bit keys) and is skipped then
+  if (hist) {
+    counts = hist;
+  } else {
+    hipLaunchKernelGGL((hist_kernel<RB, Key>), dim3(hblocks), dim3(kHistBlock), 0, st, keys_in, counts, size,
+                       size % hist_items == 0 ? hblocks : hblocks - 1, begin_bit, end_bit);
+  }
+  hipLaunchKernelGGL((scan_kernel<RB>), dim3(places), dim3(kHistBlock), 0, st, counts, hist ? hist_copies : 1,
+                     hist_copy_stride);
   const unsigned int full_blocks = size % pass_items == 0 ? blocks : blocks - 1;
   bool to_output = (places - 1) % 2 == 0;
   bool from_input = true;

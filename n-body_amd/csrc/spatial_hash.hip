@@ -26,6 +26,7 @@
 // Roofline: the build is HBM/sort bound (~48 B/body), the force kernel is VALU bound at
 // ~9 (W+2)/W rho candidate pairs per body (rho = bodies per cell), fed from L2/LDS.
 
+#include <algorithm>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -246,8 +247,15 @@ __host__ __device__ inline long long grid_cells_times(long long total, int d) {
 // host_info: the same record in pinned host memory (mapped into the device's address space): the build's one host
 // round trip then needs only the stream synchronisation, not a device-to-host copy on top (a 40-byte
 // hipMemcpyAsync ran as a 27 us copy kernel)
+// (both grid_info kernels also zero the sort's digit counts, which assign_cells_kernel then accumulates: kHistWords)
+constexpr int kHistPlaces = 3;  // grids hold < 1e8 cells = 27 key bits = three 10-bit digits
+constexpr int kHistWords = kHistPlaces << NBH_HASH_RADIX_BITS;
+constexpr int kHistCopies = onesweep::DigitHistogram<NBH_HASH_RADIX_BITS>::kCopies;
+constexpr int kHistThreads = NBH_HIST_THREADS;  // workgroup of the key kernel (few, large workgroups: fewer flushes)
 __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cell, float pad,
-                                 GridInfo* __restrict__ info, GridInfo* __restrict__ host_info) {
+                                 GridInfo* __restrict__ info, GridInfo* __restrict__ host_info,
+                                 unsigned int* __restrict__ hist) {
+  for (int t = threadIdx.x; t < kHistWords * kHistCopies; t += blockDim.x) hist[t] = 0u;
   if (threadIdx.x != 0) return;
   GridInfo gi;
   long long total = 1;
@@ -270,7 +278,8 @@ __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cel
 
 // grid geometry decided on the host (explicit bounds: the sharded path): the record travels as a kernel argument,
 // so there is no pinned staging buffer to protect and the build needs no stream synchronisation
-__global__ void grid_info_set_kernel(GridInfo gi, GridInfo* __restrict__ info) {
+__global__ void grid_info_set_kernel(GridInfo gi, GridInfo* __restrict__ info, unsigned int* __restrict__ hist) {
+  for (int t = threadIdx.x; t < kHistWords * kHistCopies; t += blockDim.x) hist[t] = 0u;
   if (threadIdx.x == 0) *info = gi;
 }
 
@@ -279,22 +288,39 @@ __device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim
   return min(max(c, 0), dim - 1);
 }
 
-// force_spatial_hash.cu:28-49
-__global__ __launch_bounds__(kBlock) void assign_cells_kernel(const float4* __restrict__ posm, int n,
+// force_spatial_hash.cu:28-49.  The kernel that has every key in a register also does the sort's bookkeeping: it
+// zeroes the look-back block of the Onesweep passes (zero_words) and, with hist_places > 0, accumulates the digit
+// histograms (LDS, then one global atomic per non-empty bin and workgroup) -- a fill launch and rocPRIM's histogram
+// kernel (43 us at 4.2 M bodies) less.  A fixed grid strides over the bodies.
+__global__ __launch_bounds__(kHistThreads) void assign_cells_kernel(const float4* __restrict__ posm, int n,
                                                               const GridInfo* __restrict__ info,
                                                               float cell,
                                                               unsigned int* __restrict__ keys,
-                                                              unsigned int* __restrict__ zero, unsigned int zero_words) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  // what the sort wants zeroed (onesweep.h: histograms, look-back states): here instead of a fill launch
-  for (unsigned int w = i; w < zero_words; w += gridDim.x * kBlock) zero[w] = 0u;
-  if (i >= n) return;
-  const float4 p = posm[i];
+                                                              unsigned int* __restrict__ zero, unsigned int zero_words,
+                                                              unsigned int* __restrict__ hist, int hist_places) {
+  using Hist = onesweep::DigitHistogram<NBH_HASH_RADIX_BITS>;
+  __shared__ unsigned int h[kHistWords];
+  const int stride = gridDim.x * kHistThreads;
+  for (unsigned int w = blockIdx.x * kHistThreads + threadIdx.x; w < zero_words; w += stride) zero[w] = 0u;
+  if (hist_places) {
+    Hist::zero(h, hist_places, threadIdx.x, kHistThreads);
+    __syncthreads();
+  }
   const int gx = info->dims[0], gy = info->dims[1], gz = info->dims[2];
-  const int cx = cell_coord(p.x, info->bmin[0], cell, gx);
-  const int cy = cell_coord(p.y, info->bmin[1], cell, gy);
-  const int cz = cell_coord(p.z, info->bmin[2], cell, gz);
-  keys[i] = (unsigned int)(cx + cy * gx + cz * gx * gy);
+  const float lx = info->bmin[0], ly = info->bmin[1], lz = info->bmin[2];
+  for (int i = blockIdx.x * kHistThreads + threadIdx.x; i < n; i += stride) {
+    const float4 p = posm[i];
+    const int cx = cell_coord(p.x, lx, cell, gx);
+    const int cy = cell_coord(p.y, ly, cell, gy);
+    const int cz = cell_coord(p.z, lz, cell, gz);
+    const unsigned int key = (unsigned int)(cx + cy * gx + cz * gx * gy);
+    keys[i] = key;
+    if (hist_places) Hist::add(h, key, hist_places);
+  }
+  if (hist_places) {
+    __syncthreads();
+    Hist::flush(h, hist_places, threadIdx.x, kHistThreads, hist, kHistWords);
+  }
 }
 
 // Per-cell start array: cell_lb[c - base] = number of bodies whose cell id is below c (= sorted position of the
@@ -793,7 +819,8 @@ using namespace nbh;
 // stable radix sort of the cell ids carrying (body, original index) along; temp == nullptr: size query
 static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned int* keys_in, unsigned int* keys_out,
                                       const float4* bodies_in, float4* bodies_out, int* idx_out, size_t n, int bits,
-                                      hipStream_t st, size_t own_from = nbh::kOwnSortFromGrid, bool cleared = false) {
+                                      hipStream_t st, size_t own_from = nbh::kOwnSortFromGrid, bool cleared = false,
+                                      unsigned int* hist = nullptr) {
   auto vin = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_in, rocprim::make_counting_iterator<int>(0)));
   auto vout = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_out, idx_out));
 #if NBH_HASH_OWN_SORT
@@ -809,7 +836,7 @@ static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned i
   }
   if (n >= own_from)
     return nbh::onesweep::sort_pairs<NBH_HASH_RADIX_BITS>(temp, temp_bytes, static_cast<const unsigned int*>(keys_in), keys_out,
-                                                          vin, vout, n, 0u, (unsigned)bits, st, cleared);
+                                                          vin, vout, n, 0u, (unsigned)bits, st, cleared, hist, nbh::kHistCopies, nbh::kHistWords);
 #endif
   return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vin, vout, n, 0, bits, st);
 }
@@ -828,6 +855,7 @@ struct nbody_hip_grid {
   float4* d_sorted = nullptr;
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  unsigned int* d_hist = nullptr;      // digit counts of the sort, accumulated by assign_cells_kernel (kHistWords)
   size_t own_sort_from = nbh::kOwnSortFromGrid;  // onesweep.h driver from this many bodies
   int *d_cell_start = nullptr, *d_cell_end = nullptr;  // lazily sized (inspection API only)
   long long cell_capacity = 0;
@@ -848,7 +876,7 @@ static void grid_release(nbody_hip_grid* g) {
   if (!g) return;
   (void)hipFree(g->d_enc); (void)hipFree(g->d_info); (void)hipFree(g->d_keys_a);
   (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_b);
-  (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_cell_start);
+  (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_hist); (void)hipFree(g->d_cell_start);
   (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb);
   if (g->h_info) (void)hipHostFree(g->h_info);
   delete g;
@@ -886,6 +914,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
     if (e == hipSuccess) {
       g->sort_tmp_bytes = tmp;
       e = hipMalloc(&g->d_sort_tmp, tmp > 0 ? tmp : 16);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_hist), (size_t)kHistCopies * kHistWords * sizeof(unsigned int));
     }
   }
   if (e != hipSuccess) {
@@ -937,7 +966,6 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   NBH_NOT_CAPTURABLE(ctx, "the spatial-hash grid build");
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
-  const int blocks = (ni + kBlock - 1) / kBlock;
   if (bounds) {
     GridInfo gi{};
     long long total = 1;
@@ -951,7 +979,7 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     g->info = gi;
     if (g->info.total > 100000000LL)
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
-    hipLaunchKernelGGL(grid_info_set_kernel, dim3(1), dim3(64), 0, st, gi, g->d_info);
+    hipLaunchKernelGGL(grid_info_set_kernel, dim3(1), dim3(256), 0, st, gi, g->d_info, g->d_hist);
     NBH_LAUNCH_CHECK();
   } else {
     if (soa && drift_dt) {
@@ -961,8 +989,8 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     } else {
       if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
     }
-    hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info,
-                       g->h_info_dev);
+    hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(256), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info,
+                       g->h_info_dev, g->d_hist);
     NBH_LAUNCH_CHECK();
     // the one host round trip of the build: the grid size decides validity (and, for the
     // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
@@ -975,13 +1003,17 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   const int sort_bits = bits_for(g->info.total);
   const bool own_sort = NBH_HASH_OWN_SORT && n >= g->own_sort_from;
   const size_t zero_words = own_sort ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)sort_bits) : 0;
-  hipLaunchKernelGGL(assign_cells_kernel, dim3(blocks), dim3(kBlock), 0, st, posm, ni, g->d_info,
-                     g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words);
+  const int hist_places = own_sort && sort_bits <= kHistPlaces * NBH_HASH_RADIX_BITS
+                              ? (sort_bits + NBH_HASH_RADIX_BITS - 1) / NBH_HASH_RADIX_BITS : 0;
+  hipLaunchKernelGGL(assign_cells_kernel, dim3(std::min((ni + kHistThreads - 1) / kHistThreads, NBH_HIST_BLOCKS)), dim3(kHistThreads), 0, st, posm, ni, g->d_info,
+                     g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words,
+                     g->d_hist, hist_places);
   NBH_LAUNCH_CHECK();
   size_t tmp = g->sort_tmp_bytes;
   // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
   NBH_HIP(sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n,
-                              sort_bits, st, own_sort ? (size_t)0 : ~(size_t)0, /*cleared=*/own_sort));
+                              sort_bits, st, own_sort ? (size_t)0 : ~(size_t)0, /*cleared=*/own_sort,
+                              hist_places ? g->d_hist : nullptr));
   g->lb_valid = false;
   {
     // cells the per-cell start array covers: the whole grid, or the z layers of this rank's slab
