@@ -583,7 +583,7 @@ def main():
         for key, wl, nn in (("barnes_hut", "bh", 1 << 20), ("spatial_hash", "hash", 4194304)):
             try:
                 extra[key] = run_other_workload(a, nb, ctx, world, rank, False, dist, torch, workload=wl,
-                                                n_bodies=nn, steps=20, warmup=3)
+                                                n_bodies=nn, steps=200, warmup=20)
             except Exception as e:  # the headline line must survive a failure here
                 extra[key] = {"error": f"{type(e).__name__}: {e}"}
         if out is not None:

@@ -252,7 +252,8 @@ constexpr int kHistPlaces = 3;  // grids hold < 1e8 cells = 27 key bits = three 
 constexpr int kHistWords = kHistPlaces << NBH_HASH_RADIX_BITS;
 constexpr int kHistCopies = onesweep::DigitHistogram<NBH_HASH_RADIX_BITS>::kCopies;
 constexpr int kHistThreads = NBH_HIST_THREADS;  // workgroup of the key kernel (few, large workgroups: fewer flushes)
-__global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cell, float pad,
+// ... and leave the empty box behind in enc: the next build's box pass needs no bbox_init_kernel
+__global__ void grid_info_kernel(unsigned int* __restrict__ enc, float cell, float pad,
                                  GridInfo* __restrict__ info, GridInfo* __restrict__ host_info,
                                  unsigned int* __restrict__ hist) {
   for (int t = threadIdx.x; t < kHistWords * kHistCopies; t += blockDim.x) hist[t] = 0u;
@@ -262,6 +263,8 @@ __global__ void grid_info_kernel(const unsigned int* __restrict__ enc, float cel
   for (int a = 0; a < 3; a++) {
     const float lo = ordered_to_float(enc[a]) - pad;
     const float hi = ordered_to_float(enc[3 + a]) + pad;
+    enc[a] = 0xffffffffu;
+    enc[3 + a] = 0u;
     gi.bmin[a] = lo;
     gi.bmax[a] = hi;
     const int d = grid_axis_cells(lo, hi, cell);
@@ -847,6 +850,7 @@ struct nbody_hip_grid {
   float cell_size = 1.0f;
   // device
   unsigned int* d_enc = nullptr;       // 6 ordered-int bbox words
+  bool enc_armed = false;              // d_enc holds the empty box (left by the previous build's grid_info_kernel)
   GridInfo* d_info = nullptr;
   GridInfo* h_info = nullptr;          // pinned
   GridInfo* h_info_dev = nullptr;      // the device's address of h_info (null: not mapped, copy instead)
@@ -982,16 +986,19 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
     hipLaunchKernelGGL(grid_info_set_kernel, dim3(1), dim3(256), 0, st, gi, g->d_info, g->d_hist);
     NBH_LAUNCH_CHECK();
   } else {
+    const bool armed = g->enc_armed;  // false on the first build and after one that failed before grid_info_kernel
+    g->enc_armed = false;
     if (soa && drift_dt) {
-      if (int rc = launch_drift_pack_bbox(ctx, const_cast<nbody_particle_data*>(soa), *drift_dt, posm, g->d_enc)) return rc;
+      if (int rc = launch_drift_pack_bbox(ctx, const_cast<nbody_particle_data*>(soa), *drift_dt, posm, g->d_enc, !armed)) return rc;
     } else if (soa) {
-      if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, g->d_enc)) return rc;
+      if (int rc = launch_pack_bbox(ctx, soa->pos_x, soa->pos_y, soa->pos_z, soa->mass, ni, posm, g->d_enc, !armed)) return rc;
     } else {
-      if (int rc = launch_bbox(ctx, posm, ni, g->d_enc)) return rc;
+      if (int rc = launch_bbox(ctx, posm, ni, g->d_enc, !armed)) return rc;
     }
     hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(256), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info,
                        g->h_info_dev, g->d_hist);
     NBH_LAUNCH_CHECK();
+    g->enc_armed = true;
     // the one host round trip of the build: the grid size decides validity (and, for the
     // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
     if (!g->h_info_dev) NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
