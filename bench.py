@@ -64,6 +64,7 @@ def parse():
                     help="direct = the headline metric (default); hash = BASELINE config 5 (N=4,194,304 "
                          "uniform box, spatial hash, z-slab shards + halo exchange); bh = config 4 "
                          "(N=1,048,576 two-galaxy, Barnes-Hut theta 0.5, one GPU).  hash/bh report steps/s")
+    ap.add_argument("--no-clock", action="store_true", help="do not sample rocm-smi beside the timed steps")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU (RCCL) code path even with one rank (rehearsal)")
     ap.add_argument("--sharded-host", choices=["cabi", "torch"], default="cabi",
@@ -161,6 +162,58 @@ def read_pmc_traffic():
             return json.load(f).get("direct_kernel", {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+class ClockSampler:
+    """Engine clock and package power of the GPU WHILE the timed region runs (rocm-smi from a host thread every ~0.4 s;
+    nothing touches the GPU's queues).  The Direct kernel keeps every VALU busy and runs into the 1,400 W package limit:
+    the sustained clock is 2.30-2.40 GHz depending on the box, which is the box-to-box spread of the step time
+    (DESIGN.md 6).  `roofline.clock` reports it and the roofline fraction re-priced at the clock that was actually there."""
+
+    def __init__(self):
+        import threading
+        self._stop = threading.Event()
+        self.samples = []
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def read():
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5)
+            card = next(iter(json.loads(r.stdout).values()))
+            rec = {}
+            for k, v in card.items():
+                if "sclk clock speed" in k.lower():
+                    rec["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
+                elif "power" in k.lower():
+                    rec["power_w"] = float(v)
+            return rec if "sclk_mhz" in rec else None
+        except Exception:  # no rocm-smi, no permission, another output format: the record simply has no clock
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            rec = self.read()
+            if rec:
+                self.samples.append(rec)
+            self._stop.wait(0.1)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=10)
+        busy = [r for r in self.samples if r.get("power_w", 0.0) > 600.0] or self.samples
+        if not busy:
+            return None
+        clk = sorted(r["sclk_mhz"] for r in busy)
+        pw = [r.get("power_w", 0.0) for r in busy]
+        return {"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
+                "power_w_mean": sum(pw) / len(pw), "samples": len(busy),
+                "source": "rocm-smi -c -P beside the timed steps (samples above 600 W)"}
 
 
 def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch, workload=None, n_bodies=None,
@@ -481,11 +534,13 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
+    sampler = ClockSampler().start() if (rank == 0 and world == 1 and not a.no_clock) else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    clock = sampler.stop() if sampler else None
     if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -558,6 +613,12 @@ def main():
                     "its executed flop count is lower.  launch_ms = event mean over the kernel + its "
                     "finalize epilogue",
         }
+        if clock:
+            # the same fraction against the FP32 peak at the clock the chip actually sustained (peak is quoted at 2.4 GHz)
+            clock["frac_at_sustained_clock"] = out["roofline"]["frac"] * 2400.0 / clock["sclk_mhz_median"]
+            clock["step_frac_at_sustained_clock"] = (FLOP_PER_PAIR * float(n) * n / (elapsed / a.steps) / 1e12
+                                                     / PEAK_FP32_VALU_TFLOPS * 2400.0 / clock["sclk_mhz_median"])
+            out["roofline"]["clock"] = clock
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, eps, a.cpu_seconds)
         if world == 1 and not a.no_extra and n >= 12288 and a.variant in (-1, 3):
