@@ -516,7 +516,8 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
     s->halo_bodies += x.n_halo;
     pl.z0h = pl.z_lo - 1 < 0 ? 0 : pl.z_lo - 1;
     pl.z1h = pl.z_hi + 1 > gz ? gz : pl.z_hi + 1;
-    // both grids dense enough for the per-cell start arrays of the two-grid kernel?  (the library's own test)
+    // both grids dense enough for the per-cell start arrays of the two-grid kernel?  (stricter than the library's own
+    // test, which builds them up to 16 cells per body: safe)
     pl.two_grid = (long long)(pl.z_hi - pl.z_lo) * layer_cells <= 4LL * (long long)x.n + 4096 &&
                   (x.n_halo == 0 || (long long)(pl.z1h - pl.z0h) * layer_cells <= 4LL * (long long)x.n_halo + 4096);
     two_grid_all = two_grid_all && (pl.two_grid || x.n == 0);

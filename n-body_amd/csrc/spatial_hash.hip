@@ -27,6 +27,7 @@
 // ~9 (W+2)/W rho candidate pairs per body (rho = bodies per cell), fed from L2/LDS.
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -610,11 +611,21 @@ struct CellGridView {
 // and its 13 "forward" neighbours -- and NO reactions are applied, so the output is not the force.  Its time is a
 // lower bound for any Newton's-third-law form of this kernel (half the candidate pairs, reaction arithmetic and
 // reaction traffic free); DESIGN.md section 4.4 sets it against the cost of deterministic reaction slots.
-template <bool GUARD, int R, bool HALF = false>
+//
+// UNITS: the work list of cell_units_kernel instead of the cell range itself.  A unit is (occupied cell, chunk of at
+// most 64 R of its bodies): empty cells cost nothing and a crowded cell is spread over as many waves as it has chunks
+// (a uniform box that has clumped under its own gravity holds cells of hundreds of bodies beside a majority of empty
+// ones: one wave per cell then leaves the step waiting for a few waves).  Wave w of the grid takes the unit groups
+// w, w + waves, ... of its XCD's contiguous share of the list; the host sizes the grid from the previous count, so a
+// wave usually takes one group and the hardware's dispatch order balances the load.  Chunks are the same 64 R targets
+// the cell loop forms, so both forms sum in the same order: bit-identical results.
+template <bool GUARD, int R, bool HALF = false, bool UNITS = false>
 __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
-    float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate) {
+    float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
+    const int2* __restrict__ units = nullptr, const int* __restrict__ unit_count = nullptr,
+    int* __restrict__ unit_count_host = nullptr) {
   constexpr int KC = kCellsPerWave;
   __shared__ float4 win_all[4][kWinCap];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -629,16 +640,40 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
   // that neighbouring cells, whose windows overlap, share an L2
   const long long blk = (long long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
   const long long cell0 = cell_first + (blk * 4 + w) * KC;
-  if (cell0 >= cell_end) return;
-
+  int grp = 0, grp_end = 0, n_units = 0;  // UNITS: this wave's next group of KC units, the end of its XCD's share
+  if constexpr (UNITS) {
+    n_units = __builtin_amdgcn_readfirstlane(*unit_count);
+    if (unit_count_host && blockIdx.x == 0 && threadIdx.x == 0) {  // chooses and sizes the next launch
+      unit_count_host[0] = n_units;
+      unit_count_host[1] = unit_count[1];
+    }
+    const long long groups = (n_units + KC - 1) / KC;
+    const int x = blockIdx.x & 7;
+    grp = (int)(groups * x / 8) + (int)(blockIdx.x >> 3) * 4 + w;
+    grp_end = (int)(groups * (x + 1) / 8);
+  } else {
+    if (cell0 >= cell_end) return;
+  }
+  for (; !UNITS || grp < grp_end; grp += blocks_per_xcd * 4) {
   // One round of lookups for all KC cells: lane 16 c + r.  r < 9: run r of cell c's window (cells
   // cx-1..cx+1 of row y + r%3 - 1, z + r/3 - 1): vseg0 = first sorted position, vlen = length;
-  // r = 9: vseg0 = first target of the cell, r = 10: vseg0 = end of its targets.
+  // r = 9: vseg0 = first target of the cell, r = 10: vseg0 = end of its targets (r = 11, UNITS: the chunk).
   int vseg0 = 0, vlen = 0;
   {
     const int c = lane >> 4, r = lane & 15;
-    const long long cell = cell0 + c;
-    if (c < KC && cell < cell_end) {
+    long long cell = cell0 + c;
+    bool have = c < KC && cell < cell_end;
+    int chunk = 0;
+    if constexpr (UNITS) {
+      const int u = grp * KC + c;
+      have = c < KC && u < n_units;
+      if (have) {
+        const int2 uu = units[u];
+        cell = cell_first + uu.x;
+        chunk = uu.y;
+      }
+    }
+    if (have) {
       if (r < 9) {
         // (32-bit: a grid holds at most 1e8 cells; the 64-bit divisions this replaces were ~100 instructions each)
         const unsigned int c32 = (unsigned int)cell, layer = (unsigned int)gx * (unsigned int)gy;
@@ -652,6 +687,8 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
         }
       } else if (r < 11) {
         vseg0 = tgv.lower(cell + (r - 9));
+      } else if (r == 11) {
+        vseg0 = chunk;
       }
     }
   }
@@ -681,7 +718,11 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
 
 #pragma unroll
   for (int c = 0; c < KC; c++) {
-    const int t0 = NBH_SEG0(c, 9), t1 = NBH_SEG0(c, 10);
+    int t0 = NBH_SEG0(c, 9), t1 = NBH_SEG0(c, 10);
+    if constexpr (UNITS) {  // one chunk of the cell's bodies
+      t0 += NBH_SEG0(c, 11) * (64 * R);
+      t1 = min(t1, t0 + 64 * R);
+    }
     const int Lw = NBH_PRE(c, 9);
     bool prefetched = true;  // the registers pf hold batch 0 of this cell
     for (int tb = t0; tb < t1; tb += 64 * R) {
@@ -791,6 +832,9 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       NBH_PREFETCH(c + 1)
     }
   }
+    if constexpr (!UNITS) break;
+    __builtin_amdgcn_wave_barrier();
+  }
 #undef NBH_SEG0
 #undef NBH_PRE
 #undef NBH_PREFETCH
@@ -864,6 +908,17 @@ struct nbody_hip_grid {
   int *d_cell_start = nullptr, *d_cell_end = nullptr;  // lazily sized (inspection API only)
   long long cell_capacity = 0;
   int* d_cell_lb = nullptr;            // first sorted position of every cell (+ 1 entry); dense grids only
+  // the unit form of the wave-per-cell kernel (cell_units_kernel): work list, its two alternating counters, and
+  // the previous lists' lengths in mapped host memory (they size the next launch; a stale value costs time, not results)
+  int2* d_units = nullptr;
+  size_t units_cap = 0;
+  int* d_unit_count = nullptr;         // [2][2]: {units, bodies of the most crowded cell}, alternating
+  int* h_unit_hint = nullptr;          // pinned [2][2]: the same for whole-range calls / layer-range calls
+  int* h_unit_hint_dev = nullptr;
+  unsigned unit_flip = 0;
+  unsigned stat_tick = 0;
+  int use_units = 1;                   // NBH_HASH_UNITS in the environment at creation: 0 = never (the cell-range form,
+                                       // A/B), 2 = always (tests), default 1 = by the statistics of the previous call
   long long lb_capacity = 0;
   bool lb_valid = false;
   long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
@@ -881,7 +936,8 @@ static void grid_release(nbody_hip_grid* g) {
   (void)hipFree(g->d_enc); (void)hipFree(g->d_info); (void)hipFree(g->d_keys_a);
   (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_b);
   (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_hist); (void)hipFree(g->d_cell_start);
-  (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb);
+  (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb); (void)hipFree(g->d_units); (void)hipFree(g->d_unit_count);
+  if (g->h_unit_hint) (void)hipHostFree(g->h_unit_hint);
   if (g->h_info) (void)hipHostFree(g->h_info);
   delete g;
 }
@@ -919,6 +975,18 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
       g->sort_tmp_bytes = tmp;
       e = hipMalloc(&g->d_sort_tmp, tmp > 0 ? tmp : 16);
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_hist), (size_t)kHistCopies * kHistWords * sizeof(unsigned int));
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_unit_count), 4 * sizeof(int));
+      if (e == hipSuccess) e = hipMemset(g->d_unit_count, 0, 4 * sizeof(int));
+      if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_unit_hint), 4 * sizeof(int), hipHostMallocMapped);
+      if (e == hipSuccess) {
+        for (int k = 0; k < 4; k++) g->h_unit_hint[k] = 0;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->h_unit_hint_dev), g->h_unit_hint, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          g->h_unit_hint_dev = nullptr;
+        }
+        const char* env = std::getenv("NBH_HASH_UNITS");
+        g->use_units = env && env[0] == '0' ? 0 : (env && env[0] == '2' ? 2 : 1);
+      }
     }
   }
   if (e != hipSuccess) {
@@ -1033,7 +1101,9 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       base = z0 * layer;
       count = z1 > z0 ? (z1 - z0) * layer : 0;
     }
-    const bool dense = count > 0 && count <= 4LL * (long long)n + 4096;  // gaps a thread fills are short
+    // (16 cells per body: a box that has expanded and clumped is still walked cell by cell, with the empty cells skipped by
+    // the unit list; beyond that the start array itself -- one search per cell -- costs more than the cell-run kernel's)
+    const bool dense = count > 0 && count <= 16LL * (long long)n + 4096;
     if (dense && count + 1 > g->lb_capacity) {
       NBH_HIP(hipStreamSynchronize(st));
       (void)hipFree(g->d_cell_lb);
@@ -1109,16 +1179,139 @@ extern "C" int nbody_hip_grid_build_packed(nbody_hip_grid* g, const nbody_float4
                            bounds != nullptr);
 }
 
+namespace nbh {
+// The work list of the unit form of hash_cell_force_kernel: one thread per cell of [cell_first, cell_end); a cell with
+// cnt > 0 bodies appends ceil(cnt / chunk) units {cell - cell_first, chunk index}.  A workgroup scans its 256 counts
+// and takes ONE slot range with an atomic (the list is in cell order inside a workgroup and in about cell order over
+// all; the order does not reach the results: every target body belongs to exactly one unit).  count_next: the counter
+// of the NEXT list, zeroed here (two counters alternate: no fill launch).
+__global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView tgv, long long cell_first, long long cell_end,
+                                                            int chunk, int2* __restrict__ units, int capacity,
+                                                            int* __restrict__ count, int* __restrict__ count_next) {
+  // count[0]: units, count[1]: bodies of the most crowded cell (the host reads both, one call late, to choose the
+  // kernel form and to size its grid)
+  __shared__ int wsum[kBlock / 64], wmax[kBlock / 64];
+  __shared__ int base_s;
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) { count_next[0] = 0; count_next[1] = 0; }
+  int nu = 0, cnt = 0;
+  if (cell_first + i < cell_end) {
+    cnt = tgv.lower(cell_first + i + 1) - tgv.lower(cell_first + i);
+    nu = (cnt + chunk - 1) / chunk;
+  }
+  int mx = cnt;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+  int incl = nu;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int up = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += up;
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 63) { wsum[wv] = incl; wmax[wv] = mx; }
+  __syncthreads();
+  int before = 0, total = 0, bmax = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; k++) {
+    if (k < wv) before += wsum[k];
+    total += wsum[k];
+    bmax = max(bmax, wmax[k]);
+  }
+  if (threadIdx.x == 0) {
+    base_s = total ? atomicAdd(count, total) : 0;
+    if (bmax > 64) atomicMax(count + 1, bmax);  // (only crowded cells matter: most workgroups skip the atomic)
+  }
+  __syncthreads();
+  int at = base_s + before + incl - nu;
+  for (int k = 0; k < nu; k++, at++)
+    if (at < capacity) units[at] = make_int2((int)i, k);
+}
+// the list's statistics for the host when the force kernel that follows is not the unit form (which exports them itself)
+__global__ void cell_units_export_kernel(const int* __restrict__ count, int* __restrict__ host) {
+  if (threadIdx.x == 0) { host[0] = count[0]; host[1] = count[1]; }
+}
+}  // namespace nbh
+
+// the work list of the cells [cell_first, cell_end) of grid gt (see cell_units_kernel); *cur: its two counters
+static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGridView& tv, long long cell_first,
+                          long long cell_end, int chunk, int** cur_out) {
+  const size_t nb = gt->built_count;
+  const size_t need = nb + nb / 64 + 1024;  // an occupied cell is at least one unit; chunks hold >= 64 bodies
+  if (need > gt->units_cap) {
+    NBH_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(gt->d_units);
+    gt->d_units = nullptr;
+    gt->units_cap = 0;
+    const size_t cap = gt->max_particles + gt->max_particles / 64 + 1024;
+    NBH_HIP(hipMalloc(reinterpret_cast<void**>(&gt->d_units), (cap > need ? cap : need) * sizeof(int2)));
+    gt->units_cap = cap > need ? cap : need;
+  }
+  int* cur = gt->d_unit_count + 2 * (gt->unit_flip & 1);
+  int* next = gt->d_unit_count + 2 * ((gt->unit_flip + 1) & 1);
+  gt->unit_flip++;
+  const long long cells = cell_end - cell_first;
+  hipLaunchKernelGGL(cell_units_kernel, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, tv,
+                     cell_first, cell_end, chunk, gt->d_units, (int)gt->units_cap, cur, next);
+  NBH_LAUNCH_CHECK();
+  *cur_out = cur;
+  return NBODY_HIP_OK;
+}
+
 static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const CellGridView& sv, int gx, int gy,
                               int gz, long long cell_first, long long cell_end, int kern, bool guard, float cutoff2,
-                              float eps2, float G, float* ax, float* ay, float* az, float4* acc4, int accumulate) {
+                              float eps2, float G, float* ax, float* ay, float* az, float4* acc4, int accumulate,
+                              nbody_hip_grid* gt = nullptr, int hint_slot = 0) {
   if (cell_end <= cell_first) return NBODY_HIP_OK;
   const long long nblk = (cell_end - cell_first + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
-  const int per_xcd = (int)((nblk + 7) / 8);
-#define NBH_CELL_LAUNCH(GD, RR)                                                                        \
-  hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,    \
-                     ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, \
-                     az, acc4, accumulate)
+  int per_xcd = (int)((nblk + 7) / 8);
+  // The unit list (occupied cells in chunks of 64 R bodies) is what the kernel takes when the previous call of this
+  // kind saw crowded cells (> 64 bodies) or many empty ones; while the bodies are spread evenly it takes the cell range
+  // itself and the list is only made every eighth call, for its statistics (list + export are 19 us at 4.2 M bodies).
+  const bool can_list = gt && gt->use_units && kern != 5 && cell_end - cell_first < 0x7fffffffLL;
+  bool by_units = false;
+  const int2* units = nullptr;
+  const int* ucount = nullptr;
+  int* uhint = nullptr;
+  if (can_list) {
+    const int R = kern == 2 ? 1 : (kern == 4 ? 4 : 2);
+    const size_t nb = gt->built_count;
+    const long long cells = cell_end - cell_first;
+    uhint = gt->h_unit_hint_dev ? gt->h_unit_hint_dev + 2 * hint_slot : nullptr;
+    const int hint = uhint ? gt->h_unit_hint[2 * hint_slot] : 0, crowd = uhint ? gt->h_unit_hint[2 * hint_slot + 1] : 0;
+    by_units = gt->use_units == 2 || (hint > 0 && (crowd > 64 || (long long)hint * 10 < cells * 9));
+    if (by_units || (uhint && (gt->stat_tick++ & 7) == 0)) {
+      int* cur = nullptr;
+      if (int rc = make_unit_list(ctx, gt, tv, cell_first, cell_end, 64 * R, &cur)) return rc;
+      units = gt->d_units;
+      ucount = cur;
+      if (!by_units) {
+        hipLaunchKernelGGL(cell_units_export_kernel, dim3(1), dim3(64), 0, ctx->stream, cur, uhint);
+        NBH_LAUNCH_CHECK();
+      }
+    }
+    if (by_units) {
+      // grid: one group of KC units per wave for the list length the previous call of this kind saw (+ 1/64); the
+      // kernel strides if the list is longer.  Never more than the cells / bodies allow.
+      long long bound = (long long)(cells < (long long)nb ? cells : (long long)nb) + (long long)(nb / (64 * R)) + 1;
+      long long est = hint > 0 ? (long long)hint + hint / 64 + 64 : bound;
+      if (est > bound) est = bound;
+      long long blocks = (est + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
+      if (blocks < 8) blocks = 8;
+      per_xcd = (int)((blocks + 7) / 8);
+    }
+  }
+#define NBH_CELL_LAUNCH(GD, RR)                                                                                  \
+  do {                                                                                                           \
+    if (by_units)                                                                                                \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR, false, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
+                         ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
+                         acc4, accumulate, units, ucount, uhint);                                                \
+    else                                                                                                         \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,        \
+                         ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
+                         acc4, accumulate);                                                                      \
+  } while (0)
   if (kern == 5) {  // timing probe (see the kernel): not forces
     hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, ctx->stream, tv,
                        sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az, acc4, accumulate);
@@ -1157,11 +1350,29 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   // is denser): sphere of 10,000 in a 21^3 grid, rho 1.1, cutoff 2 > cell: 0.050 vs 0.018 ms; 100,000 bodies,
   // rho 10.8, cutoff 2: 0.86 vs 0.10 ms (the cell-run kernel's |cx_j - cx_i| test); rho 1.5 / 1.9: 0.079 /
   // 0.78 vs 0.069 / 0.47 ms.  Uniform box at rho 0.9: 0.16 (cell runs) vs 0.28 ms.
-  if (kern == 0) kern = !g->lb_valid || rho < (strict ? 0.5 : 1.0) ? 1 : (rho < 8.0 ? 2 : 3);
+  // ... and with the unit list the wave-per-cell kernel skips empty cells and spreads crowded ones, so what counts
+  // is the occupancy of the OCCUPIED cells and whether any cell is crowded (both known from the previous call): a box
+  // that has expanded and clumped (mean 0.2 bodies per cell, cells of 300 beside a majority of empty ones) runs 3.5 ms
+  // with it against 4.9 ms with the cell-run kernel; an evenly sparse box stays with the cell-run kernel.
+  const bool stats = g->lb_valid && g->use_units && g->h_unit_hint_dev;
+  const int seen_units = stats ? g->h_unit_hint[0] : 0, seen_crowd = stats ? g->h_unit_hint[1] : 0;
+  if (kern == 0) {
+    const double rho_occ = seen_units > 0 ? (double)n / (double)seen_units : rho;
+    if (!g->lb_valid || (seen_crowd <= 64 && rho < (strict ? 0.5 : 1.0))) kern = 1;
+    else kern = rho_occ < 8.0 ? 2 : 3;
+  }
   if (kern != 1 && g->lb_valid) {
     const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
     return launch_cell_forces(ctx, view, view, gx, gy, gz, g->lb_base, g->lb_base + g->lb_count, kern, guard, cutoff2,
-                              eps2, G, ax, ay, az, acc4, 0);
+                              eps2, G, ax, ay, az, acc4, 0, g, 0);
+  }
+  if (stats && g->lb_base + g->lb_count - g->lb_base < 0x7fffffffLL && (g->stat_tick++ & 7) == 0) {
+    // the cell-run kernel it is: every eighth call still looks at the occupancies (clumps form over hundreds of steps)
+    const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
+    int* cur = nullptr;
+    if (int rc = make_unit_list(ctx, g, view, g->lb_base, g->lb_base + g->lb_count, 64, &cur)) return rc;
+    hipLaunchKernelGGL(cell_units_export_kernel, dim3(1), dim3(64), 0, ctx->stream, cur, g->h_unit_hint_dev);
+    NBH_LAUNCH_CHECK();
   }
 #define NBH_HASH_LAUNCH(GD, ST)                                                                   \
   hipLaunchKernelGGL((hash_force_kernel<GD, ST>), grid, dim3(kBlock), 0, ctx->stream, g->d_sorted, \
@@ -1241,7 +1452,7 @@ extern "C" int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* gt, nbody_hip_g
   const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
   const CellGridView sv{gs->d_sorted, gs->d_cell_lb, gs->d_idx_b, gs->lb_base, gs->lb_count};
   return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f, cutoff2, eps2, G, nullptr, nullptr,
-                            nullptr, reinterpret_cast<float4*>(acc_out), accumulate ? 1 : 0);
+                            nullptr, reinterpret_cast<float4*>(acc_out), accumulate ? 1 : 0, gt, accumulate ? 1 : 0);
 }
 
 extern "C" int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t n,

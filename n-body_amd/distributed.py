@@ -563,7 +563,7 @@ class ShardedHashSystem:
             work = dist.all_to_all_single(halo, out, output_split_sizes=r_split, input_split_sizes=s_split,
                                           group=self.group, async_op=True)
         # own x own while the halo layers are in flight -- if both grids are dense enough for the per-cell start
-        # arrays of the two-grid kernel (the library's test: cells covered <= 4 bodies + 4096).  Decided HERE, from
+        # arrays of the two-grid kernel (stricter than the library's test, cells covered <= 16 bodies + 4096: safe).  Decided HERE, from
         # the layer histogram, before anything is launched: a grid that turns out too sparse after own x own has
         # run would throw that work away.
         acc_new = self._buf["acc2"][:n_new]

@@ -431,3 +431,69 @@ def test_grid_too_large_with_non_finite_positions(nb, ctx, bad):
     bounds = (C.c_float * 6)(-1e38, -1e38, -1e38, 1e38, 1e38, 1e38)  # finite extent, 2^30 cells per axis
     with pytest.raises(nb.NBodyError, match="too large"):
         check(ctx._lib.nbody_hip_grid_build_packed(grid._h, p.data_ptr(), 1000, bounds))
+
+
+# ---- the unit form of the wave-per-cell kernel (occupied cells in chunks of 64 R bodies; csrc/spatial_hash.hip) --------
+def _clumpy_box(nb, n, seed):
+    """a uniform box with dense knots in it: cells of several hundred bodies beside many empty ones"""
+    rng = np.random.default_rng(seed)
+    half = 12.0
+    ic = nb.ic.uniform_box(n, seed=seed, lo=-half, hi=half, min_mass=0.5, max_mass=1.5)
+    knots = rng.uniform(-half + 1, half - 1, (12, 3))
+    k = n // 3
+    which = rng.integers(0, len(knots), k)
+    off = rng.normal(0.0, 0.35, (k, 3))
+    for a, key in enumerate(("pos_x", "pos_y", "pos_z")):
+        ic[key][:k] = (knots[which, a] + off[:, a]).astype(np.float32)
+    return ic
+
+
+# Every body against the oracle with the unit form forced (NBH_HASH_UNITS=2), with the cell-range form (=0) and with
+# the automatic choice, which takes the list from the second call on (crowded cells seen by the first): identical
+# arithmetic order in all three, so the results are equal bit for bit, chunked cells included.
+@pytest.mark.parametrize("cell,cutoff", [(1.0, 1.0), (1.0, 1.7)])
+def test_unit_form_of_the_cell_kernel_on_clumped_bodies(nb, oracle, ctx, monkeypatch, cell, cutoff):
+    n = 60000
+    ic = _clumpy_box(nb, n, 5)
+    eps = 0.05
+    ref, gold, kappa = oracle.spatial_hash_forces_cond(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                                       float(np.float32(eps) ** 2), cell, cutoff)
+    got = {}
+    for mode in ("2", "0", "1"):
+        monkeypatch.setenv("NBH_HASH_UNITS", mode)
+        d, _ = to_device(nb, ic)
+        calc = nb.SpatialHashCalculator(cell, cutoff)
+        calc.setSofteningParameter(eps)
+        calc.computeForces(d)                      # (the grid is made here, with the mode of the environment)
+        for kernel in (3, 2):                      # two targets per lane (chunks of 128), one (chunks of 64)
+            calc.getGrid().tuning(kernel)
+            calc.computeForces(d)                  # (automatic mode: this call has seen the first one's statistics)
+            got[mode, kernel] = acc_of(d)
+        counts = np.diff(np.stack(calc.getGrid().copyCellDataToHost()[:2]), axis=0)[0]
+        assert counts.max() > 300 and (counts == 0).mean() > 0.15      # chunked cells and empty cells are both there
+    for kernel in (3, 2):
+        assert np.array_equal(got["2", kernel], got["0", kernel]) and np.array_equal(got["1", kernel], got["0", kernel])
+    nz = np.linalg.norm(ref, axis=1) > 0
+    a = got["2", 3]
+    assert np.all(a[~nz] == 0)
+    e = rel_err(a[nz], ref[nz])
+    assert np.all(e <= np.maximum(TOL, 3 * U * kappa[nz])), e.max()
+
+
+# ... and through the steps of a system whose statistics change under it: the form is chosen anew at every call
+def test_unit_form_follows_the_statistics(nb, ctx, monkeypatch):
+    monkeypatch.setenv("NBH_HASH_UNITS", "1")
+    n = 40000
+    ic = _clumpy_box(nb, n, 9)
+    a = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NBH_HASH_UNITS", mode)
+        ps = nb.ParticleSystem()
+        ps.initialize(nb.SimulationConfig(particle_count=n, dt=1e-3, force_method=nb.ForceMethod.SPATIAL_HASH, softening=0.05,
+                                          spatial_hash_cell_size=1.0, spatial_hash_cutoff=1.0), initial_conditions=ic)
+        for _ in range(12):
+            ps.update(1e-3)
+        torch.cuda.synchronize()
+        a[mode] = {k: getattr(ps.d_particles_, k).cpu().numpy() for k in ("pos_x", "vel_y", "acc_z")}
+    for k in a["1"]:
+        assert np.array_equal(a["1"][k], a["0"][k]), k
