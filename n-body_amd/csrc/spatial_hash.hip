@@ -361,6 +361,38 @@ __global__ __launch_bounds__(kBlock) void cell_lb_kernel(const unsigned int* __r
   cell_lb[t] = lo;
 }
 
+// The same array for grids with more cells than bodies, where the bodies are anything but evenly spread (a box that
+// has expanded and clumped: 22 M cells for 4.2 M bodies, cells of 400 beside a majority of empty ones) and the
+// uniform-density guess above is off by 10^5 positions: ~30 dependent probes per cell, 0.42 ms.  Two levels instead:
+// every 64th cell by a full binary search, then every cell inside the bracket its two neighbours of the coarse level
+// give (the bodies of 64 cells: a handful of probes).
+constexpr int kLbCoarse = 64;
+__global__ __launch_bounds__(kBlock) void cell_lb_coarse_kernel(const unsigned int* __restrict__ keys, int n, int base,
+                                                                int count, int* __restrict__ coarse) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;  // cell base + t * kLbCoarse
+  const int ncoarse = count / kLbCoarse + 2;  // entries floor(t / 64) and + 1 for every t in [0, count]
+  if (t >= ncoarse) return;
+  const long long c = (long long)base + (long long)t * kLbCoarse;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((long long)keys[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  coarse[t] = lo;
+}
+__global__ __launch_bounds__(kBlock) void cell_lb_fine_kernel(const unsigned int* __restrict__ keys, int base, int count,
+                                                              const int* __restrict__ coarse, int* __restrict__ cell_lb) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t > count) return;
+  const unsigned int c = (unsigned int)(base + t);
+  int lo = coarse[t / kLbCoarse], hi = coarse[t / kLbCoarse + 1];  // keys[lo - 1] < first cell of the bracket <= c
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  cell_lb[t] = lo;
+}
+
 // per-cell [start, end) for the inspection API (copyCellDataToHost); empty cells stay 0/0
 __global__ __launch_bounds__(kBlock) void cell_ranges_kernel(const unsigned int* __restrict__ keys,
                                                              int n, int* __restrict__ cell_start,
@@ -1110,12 +1142,21 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       g->d_cell_lb = nullptr;
       g->lb_capacity = 0;
       const long long cap = (count + 1) + (count + 1) / 2;  // grids grow and shrink with the box
-      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)cap * sizeof(int)));
+      // (+ the coarse level of the two-level search behind it)
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)(cap + cap / kLbCoarse + 4) * sizeof(int)));
       g->lb_capacity = cap;
     }
-    if (dense)
+    if (dense && count > 2LL * (long long)n) {  // more cells than bodies: two-level search (see cell_lb_coarse_kernel)
+      int* coarse = g->d_cell_lb + g->lb_capacity;
+      const long long ncoarse = count / kLbCoarse + 2;
+      hipLaunchKernelGGL(cell_lb_coarse_kernel, dim3((unsigned)((ncoarse + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                         g->d_keys_b, ni, (int)base, (int)count, coarse);
+      hipLaunchKernelGGL(cell_lb_fine_kernel, dim3((unsigned)((count + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                         g->d_keys_b, (int)base, (int)count, coarse, g->d_cell_lb);
+    } else if (dense) {
       hipLaunchKernelGGL(cell_lb_kernel, dim3((unsigned)((count + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, ni, (int)base, (int)count, g->d_cell_lb);
+    }
     NBH_LAUNCH_CHECK();
     if (dense) {
       g->lb_valid = true;
@@ -1185,6 +1226,8 @@ namespace nbh {
 // and takes ONE slot range with an atomic (the list is in cell order inside a workgroup and in about cell order over
 // all; the order does not reach the results: every target body belongs to exactly one unit).  count_next: the counter
 // of the NEXT list, zeroed here (two counters alternate: no fill launch).
+constexpr int kUnitCells = 8;  // consecutive cells per thread (one slot-range atomic per 2,048 cells: a workgroup per
+                               // 256 cells made 86,000 atomics on one word at 22 M cells, 0.44 ms)
 __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView tgv, long long cell_first, long long cell_end,
                                                             int chunk, int2* __restrict__ units, int capacity,
                                                             int* __restrict__ count, int* __restrict__ count_next) {
@@ -1192,14 +1235,25 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
   // kernel form and to size its grid)
   __shared__ int wsum[kBlock / 64], wmax[kBlock / 64];
   __shared__ int base_s;
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i == 0) { count_next[0] = 0; count_next[1] = 0; }
-  int nu = 0, cnt = 0;
-  if (cell_first + i < cell_end) {
-    cnt = tgv.lower(cell_first + i + 1) - tgv.lower(cell_first + i);
-    nu = (cnt + chunk - 1) / chunk;
+  const long long i0 = ((long long)blockIdx.x * kBlock + threadIdx.x) * kUnitCells;
+  if (i0 == 0) { count_next[0] = 0; count_next[1] = 0; }
+  int nus[kUnitCells];
+  int nu = 0, mx = 0;
+  {
+    int lo = cell_first + i0 < cell_end ? tgv.lower(cell_first + i0) : 0;
+#pragma unroll
+    for (int k = 0; k < kUnitCells; k++) {
+      nus[k] = 0;
+      if (cell_first + i0 + k < cell_end) {
+        const int hi = tgv.lower(cell_first + i0 + k + 1);
+        const int cnt = hi - lo;
+        lo = hi;
+        nus[k] = (cnt + chunk - 1) / chunk;
+        nu += nus[k];
+        mx = max(mx, cnt);
+      }
+    }
   }
-  int mx = cnt;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
   int incl = nu;
@@ -1224,8 +1278,10 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
   }
   __syncthreads();
   int at = base_s + before + incl - nu;
-  for (int k = 0; k < nu; k++, at++)
-    if (at < capacity) units[at] = make_int2((int)i, k);
+#pragma unroll
+  for (int k = 0; k < kUnitCells; k++)
+    for (int q = 0; q < nus[k]; q++, at++)
+      if (at < capacity) units[at] = make_int2((int)(i0 + k), q);
 }
 // the list's statistics for the host when the force kernel that follows is not the unit form (which exports them itself)
 __global__ void cell_units_export_kernel(const int* __restrict__ count, int* __restrict__ host) {
@@ -1251,7 +1307,7 @@ static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGrid
   int* next = gt->d_unit_count + 2 * ((gt->unit_flip + 1) & 1);
   gt->unit_flip++;
   const long long cells = cell_end - cell_first;
-  hipLaunchKernelGGL(cell_units_kernel, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, tv,
+  hipLaunchKernelGGL(cell_units_kernel, dim3((unsigned)((cells + kBlock * kUnitCells - 1) / (kBlock * kUnitCells))), dim3(kBlock), 0, ctx->stream, tv,
                      cell_first, cell_end, chunk, gt->d_units, (int)gt->units_cap, cur, next);
   NBH_LAUNCH_CHECK();
   *cur_out = cur;

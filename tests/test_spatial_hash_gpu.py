@@ -497,3 +497,27 @@ def test_unit_form_follows_the_statistics(nb, ctx, monkeypatch):
         a[mode] = {k: getattr(ps.d_particles_, k).cpu().numpy() for k in ("pos_x", "vel_y", "acc_z")}
     for k in a["1"]:
         assert np.array_equal(a["1"][k], a["0"][k]), k
+
+
+# more cells than bodies, bodies in knots: the start arrays come from the two-level search and the unit form skips the
+# empty cells -- every body against the oracle, and equal to the cell-range form on the guess-based start arrays' side
+# of the threshold (a grid of fewer cells over the same bodies)
+def test_sparse_clumped_grid_against_the_oracle(nb, oracle, ctx, monkeypatch):
+    n = 30000
+    ic = _clumpy_box(nb, n, 11)
+    eps, cutoff = 0.05, 0.4
+    for cell in (0.4, 0.5):                        # 61^3 = 227,000 cells (> 2 n: two levels), 49^3 = 118,000 (guess)
+        ref, gold, kappa = oracle.spatial_hash_forces_cond(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], 1.0,
+                                                           float(np.float32(eps) ** 2), cell, cutoff)
+        for mode in ("2", "1"):
+            monkeypatch.setenv("NBH_HASH_UNITS", mode)
+            d, _ = to_device(nb, ic)
+            calc = nb.SpatialHashCalculator(cell, cutoff)
+            calc.setSofteningParameter(eps)
+            calc.computeForces(d)
+            calc.computeForces(d)
+            a = acc_of(d)
+            nz = np.linalg.norm(ref, axis=1) > 0
+            assert np.all(a[~nz] == 0)
+            e = rel_err(a[nz], ref[nz])
+            assert np.all(e <= np.maximum(TOL, 3 * U * kappa[nz])), (cell, mode, e.max())
