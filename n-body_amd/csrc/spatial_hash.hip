@@ -648,16 +648,17 @@ struct CellGridView {
 // most 64 R of its bodies): empty cells cost nothing and a crowded cell is spread over as many waves as it has chunks
 // (a uniform box that has clumped under its own gravity holds cells of hundreds of bodies beside a majority of empty
 // ones: one wave per cell then leaves the step waiting for a few waves).  Wave w of the grid takes the unit groups
-// w, w + waves, ... of its XCD's contiguous share of the list; the host sizes the grid from the previous count, so a
-// wave usually takes one group and the hardware's dispatch order balances the load.  Chunks are the same 64 R targets
-// the cell loop forms, so both forms sum in the same order: bit-identical results.
+// w, w + waves, ... of the list, which holds the heavy units first; the host sizes the grid from the previous count, so
+// a wave usually takes one group and the hardware's dispatch order (workgroups in index order) does the balancing:
+// long units early, short ones in the tail.  Chunks are the same 64 R targets the cell loop forms, so both forms sum
+// in the same order: bit-identical results.
 template <bool GUARD, int R, bool HALF = false, bool UNITS = false>
 __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
     float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
     const int2* __restrict__ units = nullptr, const int* __restrict__ unit_count = nullptr,
-    int* __restrict__ unit_count_host = nullptr) {
+    int* __restrict__ unit_count_host = nullptr, int unit_capacity = 0) {
   constexpr int KC = kCellsPerWave;
   __shared__ float4 win_all[4][kWinCap];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -672,21 +673,21 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
   // that neighbouring cells, whose windows overlap, share an L2
   const long long blk = (long long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
   const long long cell0 = cell_first + (blk * 4 + w) * KC;
-  int grp = 0, grp_end = 0, n_units = 0;  // UNITS: this wave's next group of KC units, the end of its XCD's share
+  int grp = 0, grp_end = 0, n_units = 0, n_heavy = 0;  // UNITS: this wave's next group of KC units, the end of the list
   if constexpr (UNITS) {
-    n_units = __builtin_amdgcn_readfirstlane(*unit_count);
+    n_heavy = __builtin_amdgcn_readfirstlane(unit_count[0]);
+    n_units = n_heavy + __builtin_amdgcn_readfirstlane(unit_count[2]);
     if (unit_count_host && blockIdx.x == 0 && threadIdx.x == 0) {  // chooses and sizes the next launch
       unit_count_host[0] = n_units;
       unit_count_host[1] = unit_count[1];
     }
-    const long long groups = (n_units + KC - 1) / KC;
-    const int x = blockIdx.x & 7;
-    grp = (int)(groups * x / 8) + (int)(blockIdx.x >> 3) * 4 + w;
-    grp_end = (int)(groups * (x + 1) / 8);
+    // the list front to back in workgroup order (heavy units first, see cell_units_kernel)
+    grp = (int)blockIdx.x * 4 + w;
+    grp_end = (n_units + KC - 1) / KC;
   } else {
     if (cell0 >= cell_end) return;
   }
-  for (; !UNITS || grp < grp_end; grp += blocks_per_xcd * 4) {
+  for (; !UNITS || grp < grp_end; grp += blocks_per_xcd * 32) {
   // One round of lookups for all KC cells: lane 16 c + r.  r < 9: run r of cell c's window (cells
   // cx-1..cx+1 of row y + r%3 - 1, z + r/3 - 1): vseg0 = first sorted position, vlen = length;
   // r = 9: vseg0 = first target of the cell, r = 10: vseg0 = end of its targets (r = 11, UNITS: the chunk).
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       const int u = grp * KC + c;
       have = c < KC && u < n_units;
       if (have) {
-        const int2 uu = units[u];
+        const int2 uu = units[u < n_heavy ? u : unit_capacity - 1 - (u - n_heavy)];
         cell = cell_first + uu.x;
         chunk = uu.y;
       }
@@ -944,7 +945,7 @@ struct nbody_hip_grid {
   // the previous lists' lengths in mapped host memory (they size the next launch; a stale value costs time, not results)
   int2* d_units = nullptr;
   size_t units_cap = 0;
-  int* d_unit_count = nullptr;         // [2][2]: {units, bodies of the most crowded cell}, alternating
+  int* d_unit_count = nullptr;         // [2][4]: {heavy units, bodies of the most crowded cell, other units, -}, alternating
   int* h_unit_hint = nullptr;          // pinned [2][2]: the same for whole-range calls / layer-range calls
   int* h_unit_hint_dev = nullptr;
   unsigned unit_flip = 0;
@@ -1007,8 +1008,8 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
       g->sort_tmp_bytes = tmp;
       e = hipMalloc(&g->d_sort_tmp, tmp > 0 ? tmp : 16);
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_hist), (size_t)kHistCopies * kHistWords * sizeof(unsigned int));
-      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_unit_count), 4 * sizeof(int));
-      if (e == hipSuccess) e = hipMemset(g->d_unit_count, 0, 4 * sizeof(int));
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_unit_count), 8 * sizeof(int));
+      if (e == hipSuccess) e = hipMemset(g->d_unit_count, 0, 8 * sizeof(int));
       if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_unit_hint), 4 * sizeof(int), hipHostMallocMapped);
       if (e == hipSuccess) {
         for (int k = 0; k < 4; k++) g->h_unit_hint[k] = 0;
@@ -1228,17 +1229,24 @@ namespace nbh {
 // of the NEXT list, zeroed here (two counters alternate: no fill launch).
 constexpr int kUnitCells = 8;  // consecutive cells per thread (one slot-range atomic per 2,048 cells: a workgroup per
                                // 256 cells made 86,000 atomics on one word at 22 M cells, 0.44 ms)
+// Heavy first: the units of cells with more than kHeavyCell bodies (they sit in clumps: long windows too) go to the
+// FRONT of the list, the others are written from the BACK down, and the force kernel takes the list front to back -- the
+// hardware starts workgroups in index order, so the long units run first and the short ones fill the tail (longest
+// processing time first; with the plain cell order a clump late in the list left the chip waiting for it).
+constexpr int kHeavyCell = 48;
 __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView tgv, long long cell_first, long long cell_end,
                                                             int chunk, int2* __restrict__ units, int capacity,
                                                             int* __restrict__ count, int* __restrict__ count_next) {
-  // count[0]: units, count[1]: bodies of the most crowded cell (the host reads both, one call late, to choose the
-  // kernel form and to size its grid)
-  __shared__ int wsum[kBlock / 64], wmax[kBlock / 64];
-  __shared__ int base_s;
+  // count[0]: heavy units, count[1]: bodies of the most crowded cell, count[2]: the other units (the host reads the
+  // sum and the maximum, one call late, to choose the kernel form and to size its grid)
+  __shared__ int wsum[2][kBlock / 64], wmax[kBlock / 64];
+  __shared__ int base_s[2];
   const long long i0 = ((long long)blockIdx.x * kBlock + threadIdx.x) * kUnitCells;
-  if (i0 == 0) { count_next[0] = 0; count_next[1] = 0; }
+  if (i0 == 0) { count_next[0] = 0; count_next[1] = 0; count_next[2] = 0; }
   int nus[kUnitCells];
-  int nu = 0, mx = 0;
+  int nu[2] = {0, 0};  // light, heavy
+  int mx = 0;
+  unsigned heavy_mask = 0;
   {
     int lo = cell_first + i0 < cell_end ? tgv.lower(cell_first + i0) : 0;
 #pragma unroll
@@ -1249,43 +1257,52 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
         const int cnt = hi - lo;
         lo = hi;
         nus[k] = (cnt + chunk - 1) / chunk;
-        nu += nus[k];
+        const int h = cnt > kHeavyCell ? 1 : 0;
+        heavy_mask |= (unsigned)h << k;
+        nu[h] += nus[k];
         mx = max(mx, cnt);
       }
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-  int incl = nu;
+  int incl[2] = {nu[0], nu[1]};
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const int up = __shfl_up(incl, off, 64);
-    if ((int)(threadIdx.x & 63) >= off) incl += up;
+    const int u0 = __shfl_up(incl[0], off, 64), u1 = __shfl_up(incl[1], off, 64);
+    if ((int)(threadIdx.x & 63) >= off) { incl[0] += u0; incl[1] += u1; }
   }
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 63) { wsum[wv] = incl; wmax[wv] = mx; }
+  if ((threadIdx.x & 63) == 63) { wsum[0][wv] = incl[0]; wsum[1][wv] = incl[1]; wmax[wv] = mx; }
   __syncthreads();
-  int before = 0, total = 0, bmax = 0;
+  int before[2] = {0, 0}, total[2] = {0, 0}, bmax = 0;
 #pragma unroll
   for (int k = 0; k < kBlock / 64; k++) {
-    if (k < wv) before += wsum[k];
-    total += wsum[k];
+    if (k < wv) { before[0] += wsum[0][k]; before[1] += wsum[1][k]; }
+    total[0] += wsum[0][k];
+    total[1] += wsum[1][k];
     bmax = max(bmax, wmax[k]);
   }
   if (threadIdx.x == 0) {
-    base_s = total ? atomicAdd(count, total) : 0;
+    base_s[1] = total[1] ? atomicAdd(count, total[1]) : 0;
+    base_s[0] = total[0] ? atomicAdd(count + 2, total[0]) : 0;
     if (bmax > 64) atomicMax(count + 1, bmax);  // (only crowded cells matter: most workgroups skip the atomic)
   }
   __syncthreads();
-  int at = base_s + before + incl - nu;
+  int at[2] = {base_s[0] + before[0] + incl[0] - nu[0], base_s[1] + before[1] + incl[1] - nu[1]};
 #pragma unroll
-  for (int k = 0; k < kUnitCells; k++)
-    for (int q = 0; q < nus[k]; q++, at++)
-      if (at < capacity) units[at] = make_int2((int)(i0 + k), q);
+  for (int k = 0; k < kUnitCells; k++) {
+    const int h = (heavy_mask >> k) & 1;
+    for (int q = 0; q < nus[k]; q++) {
+      const int a = at[h]++;
+      const int slot = h ? a : capacity - 1 - a;  // heavy: from the front; light: from the back
+      if (slot >= 0 && slot < capacity) units[slot] = make_int2((int)(i0 + k), q);
+    }
+  }
 }
 // the list's statistics for the host when the force kernel that follows is not the unit form (which exports them itself)
 __global__ void cell_units_export_kernel(const int* __restrict__ count, int* __restrict__ host) {
-  if (threadIdx.x == 0) { host[0] = count[0]; host[1] = count[1]; }
+  if (threadIdx.x == 0) { host[0] = count[0] + count[2]; host[1] = count[1]; }
 }
 }  // namespace nbh
 
@@ -1303,8 +1320,8 @@ static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGrid
     NBH_HIP(hipMalloc(reinterpret_cast<void**>(&gt->d_units), (cap > need ? cap : need) * sizeof(int2)));
     gt->units_cap = cap > need ? cap : need;
   }
-  int* cur = gt->d_unit_count + 2 * (gt->unit_flip & 1);
-  int* next = gt->d_unit_count + 2 * ((gt->unit_flip + 1) & 1);
+  int* cur = gt->d_unit_count + 4 * (gt->unit_flip & 1);
+  int* next = gt->d_unit_count + 4 * ((gt->unit_flip + 1) & 1);
   gt->unit_flip++;
   const long long cells = cell_end - cell_first;
   hipLaunchKernelGGL(cell_units_kernel, dim3((unsigned)((cells + kBlock * kUnitCells - 1) / (kBlock * kUnitCells))), dim3(kBlock), 0, ctx->stream, tv,
@@ -1362,7 +1379,7 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
     if (by_units)                                                                                                \
       hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR, false, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
-                         acc4, accumulate, units, ucount, uhint);                                                \
+                         acc4, accumulate, units, ucount, uhint, (int)gt->units_cap);                                                \
     else                                                                                                         \
       hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,        \
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
