@@ -27,6 +27,8 @@
 // ~9 (W+2)/W rho candidate pairs per body (rho = bodies per cell), fed from L2/LDS.
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -254,9 +256,11 @@ constexpr int kHistWords = kHistPlaces << NBH_HASH_RADIX_BITS;
 constexpr int kHistCopies = onesweep::DigitHistogram<NBH_HASH_RADIX_BITS>::kCopies;
 constexpr int kHistThreads = NBH_HIST_THREADS;  // workgroup of the key kernel (few, large workgroups: fewer flushes)
 // ... and leave the empty box behind in enc: the next build's box pass needs no bbox_init_kernel
+// seq: written into the record's `pad` word LAST (after a system-scope fence): the host polls that word in the mapped
+// copy instead of waiting for the stream (see grid_build_packed)
 __global__ void grid_info_kernel(unsigned int* __restrict__ enc, float cell, float pad,
                                  GridInfo* __restrict__ info, GridInfo* __restrict__ host_info,
-                                 unsigned int* __restrict__ hist) {
+                                 unsigned int* __restrict__ hist, int seq) {
   for (int t = threadIdx.x; t < kHistWords * kHistCopies; t += blockDim.x) hist[t] = 0u;
   if (threadIdx.x != 0) return;
   GridInfo gi;
@@ -273,9 +277,13 @@ __global__ void grid_info_kernel(unsigned int* __restrict__ enc, float cell, flo
     total = grid_cells_times(total, d);
   }
   gi.total = total;
+  gi.pad = seq;
   *info = gi;
   if (host_info) {
+    gi.pad = 0;
     *host_info = gi;
+    __threadfence_system();
+    __atomic_store_n(&host_info->pad, seq, __ATOMIC_RELEASE);
     __threadfence_system();
   }
 }
@@ -929,6 +937,7 @@ struct nbody_hip_grid {
   unsigned int* d_enc = nullptr;       // 6 ordered-int bbox words
   bool enc_armed = false;              // d_enc holds the empty box (left by the previous build's grid_info_kernel)
   GridInfo* d_info = nullptr;
+  int info_seq = 0;                    // sequence number of the last grid_info_kernel (polled in h_info->pad)
   GridInfo* h_info = nullptr;          // pinned
   GridInfo* h_info_dev = nullptr;      // the device's address of h_info (null: not mapped, copy instead)
   unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
@@ -993,6 +1002,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_enc), 8 * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_info), sizeof(GridInfo));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_info), sizeof(GridInfo), hipHostMallocMapped);
+  if (e == hipSuccess) std::memset(g->h_info, 0, sizeof(GridInfo));
   if (e == hipSuccess && hipHostGetDevicePointer(reinterpret_cast<void**>(&g->h_info_dev), g->h_info, 0) != hipSuccess) {
     g->h_info_dev = nullptr;
     (void)hipGetLastError();
@@ -1097,13 +1107,29 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       if (int rc = launch_bbox(ctx, posm, ni, g->d_enc, !armed)) return rc;
     }
     hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(256), 0, st, g->d_enc, g->cell_size, 0.001f, g->d_info,
-                       g->h_info_dev, g->d_hist);
+                       g->h_info_dev, g->d_hist, ++g->info_seq);
     NBH_LAUNCH_CHECK();
     g->enc_armed = true;
     // the one host round trip of the build: the grid size decides validity (and, for the
     // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
     if (!g->h_info_dev) NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
-    NBH_HIP(hipStreamSynchronize(st));
+    if (g->h_info_dev) {
+      // poll the record's sequence word in mapped host memory: the kernel's store is visible a few microseconds after it
+      // retires, hipStreamSynchronize returned 20-30 us later (rocprofv3: the gap before assign_cells_kernel).  Bounded:
+      // after 2 ms the stream is synchronised the ordinary way (which also surfaces a fault).
+      const volatile int* seq = &g->h_info->pad;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (*seq != g->info_seq) {
+        if ((++spins & 1023u) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3)
+          break;
+      }
+      if (*seq != g->info_seq) NBH_HIP(hipStreamSynchronize(st));
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+      NBH_HIP(hipStreamSynchronize(st));
+    }
     g->info = *g->h_info;
     if (g->info.total > 100000000LL)  // :252-254
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
