@@ -318,7 +318,8 @@ __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict_
                                                             const float4* __restrict__ posm,
                                                             const int* __restrict__ sorted_idx,
                                                             float4* __restrict__ sorted,
-                                                            unsigned long long* __restrict__ plane, int G) {
+                                                            unsigned long long* __restrict__ plane,
+                                                            unsigned long long* __restrict__ cum_plane, int G) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   unsigned int mask = 0;
   if (i < n) {
@@ -345,12 +346,19 @@ __global__ __launch_bounds__(kBlock) void tree_flags_kernel(const K* __restrict_
   }
   // the wave's ballot of every level -> lane L keeps level L's and writes it with its popcount
   const int lane = threadIdx.x & 63, g = i >> 6;
-  unsigned long long mine = 0;
+  // ... and the OR of the levels 0 .. L (cum_plane[L]): the body behind the last one of a level-L node is the next
+  // position that heads a node of ANY level <= L (it heads the next node of the coarsest level that ends there), so
+  // the span pass finds a node's end as the next set bit of cum_plane[L] -- one load for all but the largest nodes
+  unsigned long long mine = 0, mine_cum = 0, run = 0;
   for (int L = 0; L <= max_depth; L++) {
     const unsigned long long b = __ballot((mask >> L) & 1u);
-    if (lane == L) mine = b;
+    run |= b;
+    if (lane == L) { mine = b; mine_cum = run; }
   }
-  if (lane <= max_depth && g < G) plane[(size_t)lane * G + g] = mine;
+  if (lane <= max_depth && g < G) {
+    plane[(size_t)lane * G + g] = mine;
+    cum_plane[(size_t)lane * G + g] = mine_cum;
+  }
 }
 
 // one workgroup per (table, level): off[L][g] <- number of flags of plane[L] before group g, totals[L] <- flags of the
@@ -403,7 +411,8 @@ __global__ __launch_bounds__(kBlock) void tree_span_kernel(const K* __restrict__
                                                            const unsigned int* __restrict__ lvlmask, LevelRanks lr,
                                                            const int* __restrict__ totals, int capacity,
                                                            int* __restrict__ last_tmp,
-                                                           unsigned long long* __restrict__ odd_plane) {
+                                                           unsigned long long* __restrict__ odd_plane,
+                                                           const unsigned long long* __restrict__ cum_plane) {
   __shared__ int ubase[kMaxDepth + 3];
   if (threadIdx.x == 0) {
     int run = 0;
@@ -420,20 +429,40 @@ __global__ __launch_bounds__(kBlock) void tree_span_kernel(const K* __restrict__
     const int pid = ubase[L] + lr.rank(L, i) - 1;
     if (pid >= capacity) continue;
     const int shift = KeyTraits<K>::kTop - 3 * L;
-    // one past the last body of the group: first j > i with another prefix
+    // one past the last body of the group = the next position that heads a node of a level <= L (tree_flags_kernel):
+    // the next set bit of cum_plane[L] behind i, looked for in this word and the next three; larger nodes (rare) fall
+    // back to the search in the keys: first j > i with another prefix
     int last = n;
     if (L > 0) {
-      const K prefix = key >> shift;
-      int lo = i + 1, hi = n;
-      // gallop first: groups are short (a node of a deep level holds a handful of bodies)
-      int step = 1;
-      while (lo + step < hi && (keys[lo + step - 1] >> shift) == prefix) { lo += step; step <<= 1; }
-      hi = min(hi, lo + step);
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((keys[mid] >> shift) == prefix) lo = mid + 1; else hi = mid;
+      const unsigned long long* cp = cum_plane + (size_t)L * lr.G;
+      const int g0 = i >> 6;
+      unsigned long long wbits = (cp[g0] >> (i & 63)) >> 1;  // flags behind i in its own word
+      int found = -1;
+      if (wbits) {
+        found = i + 1 + (__ffsll((long long)wbits) - 1);
+      } else {
+        for (int k = 1; k <= 3 && g0 + k < lr.G; k++) {
+          const unsigned long long w2 = cp[g0 + k];
+          if (w2) { found = ((g0 + k) << 6) + (__ffsll((long long)w2) - 1); break; }
+        }
       }
-      last = lo;
+      if (found >= 0) {
+        last = min(found, n);
+      } else {
+        const K prefix = key >> shift;
+        int lo = min(((g0 + 4) << 6), n), hi = n;  // (no flag up to here: the group reaches at least this far)
+        if (lo < n && (keys[lo] >> shift) == prefix) {
+          lo += 1;
+          int step = 64;
+          while (lo + step < hi && (keys[lo + step - 1] >> shift) == prefix) { lo += step; step <<= 1; }
+          hi = min(hi, lo + step);
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((keys[mid] >> shift) == prefix) lo = mid + 1; else hi = mid;
+          }
+        }
+        last = lo;
+      }
     }
     last_tmp[pid] = last;
     if (L < max_depth && last - i > leaf_max) {
@@ -1314,7 +1343,7 @@ struct nbody_hip_tree {
   int *d_idx_a = nullptr, *d_idx_b = nullptr;
   float4* d_sorted = nullptr;
   // node numbering (LevelRanks): bit planes and per-group offsets of every level, the level totals
-  unsigned long long* d_plane = nullptr;  // 2 x (max_depth + 1) * rank_G: node flags, then odd-group markers
+  unsigned long long* d_plane = nullptr;  // 3 x (max_depth + 1) * rank_G: node flags, odd-group markers, cumulative flags
   int* d_rank_off = nullptr;              // 2 x (max_depth + 1) * rank_G
   int* d_totals = nullptr;                // 2 x (kMaxDepth + 3): nodes per level, odd groups per level
   int* d_level_real = nullptr;            // kMaxDepth + 3: real nodes above every level (ids have holes)
@@ -1395,7 +1424,7 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
   const size_t nrank = 2 * (size_t)(g->max_depth + 1) * (size_t)g->rank_G;
   hipError_t e = hipMalloc(&g->d_keys_a, kbytes);
   if (e == hipSuccess) e = hipMalloc(&g->d_keys_b, kbytes);
-  if (e == hipSuccess) e = dmalloc(&g->d_plane, nrank);
+  if (e == hipSuccess) e = dmalloc(&g->d_plane, nrank + nrank / 2);  // + the cumulative planes (tree_flags_kernel)
   if (e == hipSuccess) e = dmalloc(&g->d_rank_off, nrank);
   if (e == hipSuccess) {
     size_t t1 = 0;
@@ -1622,7 +1651,7 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     int* odd_off = g->d_rank_off + tbl;
     int* odd_totals = g->d_totals + (kMaxDepth + 3);
     hipLaunchKernelGGL(tree_flags_kernel<K>, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, kb, ni,
-                       g->max_depth, g->leaf_max, lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, G);
+                       g->max_depth, g->leaf_max, lvlmask, posm, g->d_idx_b, g->d_sorted, g->d_plane, g->d_plane + 2 * tbl, G);
     if (fused && side_ok) {
       // the prefix sums of the sorted bodies only feed the monopole pass: beside the ranks + fill pass
       const int pblocks = ni / kPrefixBlock + 1;
@@ -1641,7 +1670,8 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
                        odd_plane, odd_off, odd_totals, G);
     if (g->aligned) {
       hipLaunchKernelGGL(tree_span_kernel<K>, dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
-                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->capacity, g->d_last_tmp, odd_plane);
+                         reinterpret_cast<const unsigned int*>(g->d_idx_a), lr, g->d_totals, g->capacity, g->d_last_tmp, odd_plane,
+                         g->d_plane + 2 * tbl);
       hipLaunchKernelGGL(level_scan_kernel, dim3(levels, 1), dim3(kScanBlock), 0, st, odd_plane, odd_off, odd_totals,
                          odd_plane, odd_off, odd_totals, G);
       hipLaunchKernelGGL((tree_fill_kernel<K, true>), dim3(blocks), dim3(kBlock), 0, st, kb, ni, g->max_depth, g->leaf_max,
