@@ -497,6 +497,7 @@ def main():
     else:
         csys = None
         why = ""
+        selfcheck = 0.0
         if a.sharded_host == "cabi" and a.dist_backend == "nccl" and not a.one_device:
             # the whole step behind the C ABI: RCCL communicator made from C++ (id broadcast over the process
             # group), drift -> all-gather || own x own -> shard pairs -> point-to-point reaction exchange -> kick
@@ -507,6 +508,21 @@ def main():
                 csys.set_state(ic)
                 csys.forces()
                 csys.synchronize()
+                # the exchange over RCCL with W > 1 cannot be rehearsed on a one-GPU box: before the timed steps, this
+                # rank's rows of a(0) against the one-sided kernel over ALL bodies (N^2 / W pair evaluations, ~30 ms)
+                from nbody_amd.sharded import shard_bounds
+                _, lo, hi = shard_bounds(n, world, rank)
+                mine = csys.get_state(gather=False, what=("acc",))
+                got = np.stack([mine[k][lo:hi] for k in ("acc_x", "acc_y", "acc_z")], 1)
+                pall = torch.from_numpy(np.ascontiguousarray(
+                    np.stack([ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"]], 1))).cuda()
+                ref = nb.direct_forces_packed(ctx, pall[lo:hi].contiguous(), pall, G,
+                                              float(np.float32(eps) * np.float32(eps))).cpu().numpy()[:, :3]
+                del pall
+                err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
+                if not np.all(np.isfinite(got)) or float(err.max()) > 1e-3:
+                    raise RuntimeError(f"self-check of the sharded a(0) failed on rank {rank}: max relative error {err.max():.3e}")
+                selfcheck = float(err.max())
             except Exception as e:  # every rank runs the same build: all fall back alike
                 why = f" (C-ABI host unavailable: {type(e).__name__}: {e})"
                 csys = None
@@ -518,7 +534,9 @@ def main():
             step = lambda: csys.step(dt, 1)  # noqa: E731
             path = ("C ABI (nbody_hip_sharded_direct_step): index-range shards; per step one RCCL all-gather of float4 "
                     "positions overlapped with own x own, each shard pair evaluated once by one rank, reaction blocks "
-                    "sent point-to-point to their owners, fixed-order sum fused with the kick")
+                    "sent point-to-point to their owners, fixed-order sum fused with the kick; a(0) of rank 0 checked "
+                    "against the one-sided kernel over all bodies before the timed steps: max relative error %.1e"
+                    % selfcheck)
             inner_barrier = barrier
 
             def barrier():  # noqa: F811  (the system's own streams first)
