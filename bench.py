@@ -506,8 +506,17 @@ def main():
                 comm = Comm.from_torch_distributed(local_rank)
                 csys = ShardedDirect(comm, n, G, eps)
                 csys.set_state(ic)
+                # a first evaluation that never returns (a collective one rank did not post) must not cost the caller its
+                # whole time limit: after 180 s the process says so and leaves
+                import threading
+                dog = threading.Timer(180.0, lambda: (sys.stderr.write("bench.py: the C-ABI sharded host did not finish its "
+                                                                       "first force evaluation within 180 s; run with "
+                                                                       "--sharded-host torch\n"), sys.stderr.flush(), os._exit(3)))
+                dog.daemon = True
+                dog.start()
                 csys.forces()
                 csys.synchronize()
+                dog.cancel()
                 # the exchange over RCCL with W > 1 cannot be rehearsed on a one-GPU box: before the timed steps, this
                 # rank's rows of a(0) against the one-sided kernel over ALL bodies (N^2 / W pair evaluations, ~30 ms)
                 from nbody_amd.sharded import shard_bounds
