@@ -288,3 +288,37 @@ def test_sharded_hash_one_rccl_rank_and_errors(nb, ctx):
     with pytest.raises(nb.ResourceException, match="too large"):
         c.set_state(far)
     a.close(); b.close(); c.close(); comm.close(); p2p.close()
+
+
+# a soak through the clumping of a uniform box (strong gravity, so that it happens within a few hundred steps): crowded
+# cells, an expanding grid, bodies migrating every step, the unit form of the wave-per-cell kernel inside the two-grid
+# calls and the one-grid fallback once the slabs are too sparse -- every 60 steps the accelerations the sharded system
+# holds against the single-GPU spatial hash on the system's own positions (tools/sharded_hash_soak.py is the long form)
+def test_sharded_hash_soak_through_clumping(nb, ctx):
+    from nbody_amd.sharded import Comm, ShardedHash
+    W, n, G, eps, dt = 3, 60000, 8.0, 0.02, 1e-3
+    h = 0.5 * (n / 16.0) ** (1 / 3)
+    ic = nb.ic.uniform_box(n, seed=4, lo=-h, hi=h)
+    comm = Comm.init_all(W, [0] * W)
+    sysm = ShardedHash(comm, n, G, eps, 1.0, 1.0)
+    sysm.set_state(ic)
+    sysm.forces()
+    crowded, migrated, fallback = 0, 0, False
+    for _ in range(5):
+        sysm.step(dt, 60)
+        st = sysm.get_state()
+        a1, dims = _single_gpu_hash_forces(nb, st, ic["mass"], G, eps, 1.0, 1.0)
+        a = np.stack([st["acc_x"], st["acc_y"], st["acc_z"]], 1)
+        nz = np.linalg.norm(a1, axis=1) > 0
+        assert np.all(a[~nz] == 0)
+        assert rel_err(a[nz], a1[nz]).max() < TOL
+        info = sysm.info()
+        assert tuple(info["dims"]) == tuple(dims) and sum(info["local_counts"]) == n
+        migrated += info["migrated"]
+        fallback = fallback or not info["two_grid"]
+        key = (np.floor((st["pos_x"] - st["pos_x"].min()) / 1.0).astype(np.int64) * 1000003
+               + np.floor((st["pos_y"] - st["pos_y"].min()) / 1.0).astype(np.int64)) * 1000003 \
+            + np.floor((st["pos_z"] - st["pos_z"].min()) / 1.0).astype(np.int64)
+        crowded = max(crowded, int(np.unique(key, return_counts=True)[1].max()))
+    assert migrated > 0 and crowded > 64, (migrated, crowded)   # the regime the unit form is for was reached
+    sysm.close(); comm.close()
