@@ -506,7 +506,8 @@ class SpatialHashGrid:
         self.cell_size_ = float(size)
 
     def tuning(self, kernel: int = 0):
-        """force kernel: 0 automatic, 1 cell-run, 2 / 3 wave-per-cell with 1 / 2 bodies per lane"""
+        """force kernel: 0 automatic, 1 cell-run, 2 / 3 / 4 wave-per-cell with 1 / 2 / 4 bodies per lane, 6 = 3 with the
+        window filtered by the box of the cell's bodies (crowded cells), 5 = timing probe (not forces)"""
         check(self.ctx._lib.nbody_hip_grid_tuning(self._h, kernel))
 
     def build(self, d_particles: ParticleData):

@@ -631,6 +631,7 @@ struct CellTargets<GUARD, 1> {
 // loads of cell c+1's window are already in flight (into registers), so that only the first of a
 // wave's cells pays the global-memory latency of its lookups.
 constexpr int kCellsPerWave = 4;
+constexpr double kFilterFrom = 40.0;  // bodies per occupied cell from which the filtered form pays (see FILTER below)
 
 // A grid as the force kernel sees it.  lb covers the cells [base, base + count] of the (global) grid --
 // the whole grid, or the z-slab a rank holds (sharded path); cells outside hold no bodies of this grid.
@@ -660,7 +661,16 @@ struct CellGridView {
 // a wave usually takes one group and the hardware's dispatch order (workgroups in index order) does the balancing:
 // long units early, short ones in the tail.  Chunks are the same 64 R targets the cell loop forms, so both forms sum
 // in the same order: bit-identical results.
-template <bool GUARD, int R, bool HALF = false, bool UNITS = false>
+//
+// FILTER (crowded cells: from ~40 bodies per occupied cell): window entries farther than the cutoff from the BOX of the
+// chunk's targets are left out of LDS -- they fail the cutoff test against every one of them.  Of the 27 cells' bodies
+// only 1 + 6 + 12 pi/4 + 8 pi/6 = 20.6 cells' worth can reach a unit cell at all (fewer for the tighter box of the
+// bodies): at 107 bodies per cell the kernel takes 4.6 ms instead of 5.8; at 15 per cell the per-entry box test and the
+// compacting store cost more than the quarter of the pair loop they save (1.04 against 0.94 ms), so it is a form of its
+// own.  Exact: what is kept is evaluated as before (in window order), what is dropped would have contributed 0; the
+// margin of 1e-5 covers the rounding of the two distance computations.  Not bit-identical to the unfiltered form: the
+// kept entries fall to other slices, so the partial sums group differently.
+template <bool GUARD, int R, bool HALF = false, bool UNITS = false, bool FILTER = false>
 __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
@@ -751,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
   float4 pf[9];  // first 64 entries of each run of the NEXT cell to be evaluated
 #define NBH_PREFETCH(c)                                                                              \
   _Pragma("unroll") for (int r = 0; r < 9; r++) {                                                    \
-    const int p0 = NBH_PRE(c, r), b = min(NBH_PRE(c, r + 1), kWinCap);                               \
+    const int p0 = NBH_PRE(c, r), b = FILTER ? NBH_PRE(c, r + 1) : min(NBH_PRE(c, r + 1), kWinCap);  \
     pf[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
     if (p0 < b) pf[r] = sorted[NBH_SEG0(c, r) + (min(p0 + lane, b - 1) - p0)];                       \
   }
@@ -777,12 +787,90 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       const bool live = sl < S;
       CellTargets<GUARD, R> tg;
       double sx[R], sy[R], sz[R];
+      [[maybe_unused]] float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
       for (int q = 0; q < R; q++) {
         const float4 p = tsorted[min(tb + slot + q * T, t1 - 1)];
         tg.set(q, p.x, p.y, p.z);
         sx[q] = sy[q] = sz[q] = 0.0;
+        if constexpr (FILTER) {
+          blo[0] = fminf(blo[0], p.x); bhi[0] = fmaxf(bhi[0], p.x);
+          blo[1] = fminf(blo[1], p.y); bhi[1] = fmaxf(bhi[1], p.y);
+          blo[2] = fminf(blo[2], p.z); bhi[2] = fmaxf(bhi[2], p.z);
+        }
       }
+      if constexpr (FILTER) {  // the box of the chunk's targets (every lane holds valid targets)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            blo[a] = fminf(blo[a], __shfl_xor(blo[a], off, 64));
+            bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], off, 64));
+          }
+        }
+      }
+      if constexpr (FILTER) {
+      // the pair loop over the Lb entries LDS holds
+      auto evaluate = [&](int Lb) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int iters = (Lb + S - 1) / S;
+        const float4* wp = win + (live ? sl : 0);
+        for (int i0 = 0; i0 < iters - 1; i0 += 32) {
+          const int i1 = min(i0 + 32, iters - 1);
+          tg.clear();
+#pragma unroll 4
+          for (int it = i0; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+#pragma unroll
+          for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
+        }
+        {  // the lane's last entry may lie past the batch
+          const bool valid = (int)(wp - win) < Lb;
+          float4 s = win[valid ? (int)(wp - win) : 0];
+          if (!valid) s.w = 0.f;
+          tg.clear();
+          tg.pair(s, cutoff2, eps2);
+#pragma unroll
+          for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
+        }
+        __builtin_amdgcn_wave_barrier();
+      };
+      // the window into LDS, run by run, 64 entries at a time, the entries out of reach left out (stable: the kept ones
+      // stay in window order); whenever LDS is full the pair loop runs over what it holds.  The first 64 entries of
+      // every run come from the round of loads issued while the previous cell was evaluated.
+      const float keep2 = cutoff2 * 1.00001f;
+      int wcount = 0;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        const int len = NBH_PRE(c, r + 1) - NBH_PRE(c, r), seg = NBH_SEG0(c, r);
+        for (int v = 0; v < len; v += 64) {
+          if (wcount + 64 > kWinCap) {
+            evaluate(wcount);
+            wcount = 0;
+          }
+          const bool have = v + lane < len;
+          float4 e;
+          if (v == 0 && prefetched) e = pf[r];
+          else e = sorted[seg + min(v + lane, len - 1)];
+          const float ex = fmaxf(fmaxf(blo[0] - e.x, e.x - bhi[0]), 0.f);
+          const float ey = fmaxf(fmaxf(blo[1] - e.y, e.y - bhi[1]), 0.f);
+          const float ez = fmaxf(fmaxf(blo[2] - e.z, e.z - bhi[2]), 0.f);
+          // (a NaN distance -- non-finite positions -- keeps the entry: its pairs take the ordinary path)
+          const bool keep = have && !(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > keep2);
+          const unsigned long long mask = __ballot(keep);
+          if (keep)
+            win[wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = e;
+          wcount += __builtin_amdgcn_readfirstlane(__popcll(mask));
+        }
+      }
+      if (prefetched) {
+        prefetched = false;
+        if (c + 1 < KC) { NBH_PREFETCH(c + 1) }  // in flight while this cell is evaluated
+      }
+      if (wcount) evaluate(wcount);
+      } else {
       for (int vb = 0; vb < Lw; vb += kWinCap) {
         const int Lb = min(Lw - vb, kWinCap);
         __builtin_amdgcn_wave_barrier();
@@ -829,6 +917,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
 #pragma unroll
           for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
         }
+      }
       }
       // sum over the slices
       __builtin_amdgcn_wave_barrier();
@@ -955,10 +1044,12 @@ struct nbody_hip_grid {
   int2* d_units = nullptr;
   size_t units_cap = 0;
   int* d_unit_count = nullptr;         // [2][4]: {heavy units, bodies of the most crowded cell, other units, -}, alternating
-  int* h_unit_hint = nullptr;          // pinned [2][2]: the same for whole-range calls / layer-range calls
+  int* h_unit_hint = nullptr;          // pinned [2][4]: {units, most crowded cell, sequence word, -} for whole-range calls /
+                                       // layer-range calls
   int* h_unit_hint_dev = nullptr;
   unsigned unit_flip = 0;
   unsigned stat_tick = 0;
+  int stat_seq = 0;
   int use_units = 1;                   // NBH_HASH_UNITS in the environment at creation: 0 = never (the cell-range form,
                                        // A/B), 2 = always (tests), default 1 = by the statistics of the previous call
   long long lb_capacity = 0;
@@ -1020,9 +1111,9 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_hist), (size_t)kHistCopies * kHistWords * sizeof(unsigned int));
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_unit_count), 8 * sizeof(int));
       if (e == hipSuccess) e = hipMemset(g->d_unit_count, 0, 8 * sizeof(int));
-      if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_unit_hint), 4 * sizeof(int), hipHostMallocMapped);
+      if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&g->h_unit_hint), 8 * sizeof(int), hipHostMallocMapped);
       if (e == hipSuccess) {
-        for (int k = 0; k < 4; k++) g->h_unit_hint[k] = 0;
+        for (int k = 0; k < 8; k++) g->h_unit_hint[k] = 0;
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->h_unit_hint_dev), g->h_unit_hint, 0) != hipSuccess) {
           (void)hipGetLastError();
           g->h_unit_hint_dev = nullptr;
@@ -1058,7 +1149,7 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
 }
 extern "C" int nbody_hip_grid_tuning(nbody_hip_grid* g, int kernel) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
-  if (kernel < 0 || kernel > 5) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..5");
+  if (kernel < 0 || kernel > 6) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..6");
   g->tune_kernel = kernel;
   return NBODY_HIP_OK;
 }
@@ -1327,8 +1418,17 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
   }
 }
 // the list's statistics for the host when the force kernel that follows is not the unit form (which exports them itself)
-__global__ void cell_units_export_kernel(const int* __restrict__ count, int* __restrict__ host) {
-  if (threadIdx.x == 0) { host[0] = count[0] + count[2]; host[1] = count[1]; }
+// (seq != 0: written LAST into host[2], after a system-scope fence: the host polls it)
+__global__ void cell_units_export_kernel(const int* __restrict__ count, int* __restrict__ host, int seq = 0) {
+  if (threadIdx.x == 0) {
+    host[0] = count[0] + count[2];
+    host[1] = count[1];
+    if (seq) {
+      __threadfence_system();
+      __atomic_store_n(&host[2], seq, __ATOMIC_RELEASE);
+      __threadfence_system();
+    }
+  }
 }
 }  // namespace nbh
 
@@ -1360,7 +1460,7 @@ static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGrid
 static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const CellGridView& sv, int gx, int gy,
                               int gz, long long cell_first, long long cell_end, int kern, bool guard, float cutoff2,
                               float eps2, float G, float* ax, float* ay, float* az, float4* acc4, int accumulate,
-                              nbody_hip_grid* gt = nullptr, int hint_slot = 0) {
+                              nbody_hip_grid* gt = nullptr, int hint_slot = 0, int* prebuilt = nullptr) {
   if (cell_end <= cell_first) return NBODY_HIP_OK;
   const long long nblk = (cell_end - cell_first + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
   int per_xcd = (int)((nblk + 7) / 8);
@@ -1373,15 +1473,16 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
   const int* ucount = nullptr;
   int* uhint = nullptr;
   if (can_list) {
-    const int R = kern == 2 ? 1 : (kern == 4 ? 4 : 2);
+    const int R = kern == 2 ? 1 : (kern == 4 ? 4 : 2);  // (3, 6: two)
     const size_t nb = gt->built_count;
     const long long cells = cell_end - cell_first;
-    uhint = gt->h_unit_hint_dev ? gt->h_unit_hint_dev + 2 * hint_slot : nullptr;
-    const int hint = uhint ? gt->h_unit_hint[2 * hint_slot] : 0, crowd = uhint ? gt->h_unit_hint[2 * hint_slot + 1] : 0;
-    by_units = gt->use_units == 2 || (hint > 0 && (crowd > 64 || (long long)hint * 10 < cells * 9));
+    uhint = gt->h_unit_hint_dev ? gt->h_unit_hint_dev + 4 * hint_slot : nullptr;
+    const int hint = uhint ? gt->h_unit_hint[4 * hint_slot] : 0, crowd = uhint ? gt->h_unit_hint[4 * hint_slot + 1] : 0;
+    by_units = prebuilt || gt->use_units == 2 || (hint > 0 && (crowd > 64 || (long long)hint * 10 < cells * 9));
     if (by_units || (uhint && (gt->stat_tick++ & 7) == 0)) {
-      int* cur = nullptr;
-      if (int rc = make_unit_list(ctx, gt, tv, cell_first, cell_end, 64 * R, &cur)) return rc;
+      int* cur = prebuilt;  // (the caller made this very list: one body per lane, chunks of 64)
+      if (!cur)
+        if (int rc = make_unit_list(ctx, gt, tv, cell_first, cell_end, 64 * R, &cur)) return rc;
       units = gt->d_units;
       ucount = cur;
       if (!by_units) {
@@ -1416,6 +1517,21 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
                        sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az, acc4, accumulate);
   } else if (kern == 2) { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
   else if (kern == 4) { if (guard) NBH_CELL_LAUNCH(true, 4); else NBH_CELL_LAUNCH(false, 4); }
+  else if (kern == 6) {  // two targets per lane, window filtered by the box of the targets (crowded cells)
+#define NBH_CELL_LAUNCH_F(GD)                                                                                    \
+  do {                                                                                                           \
+    if (by_units)                                                                                                \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, 2, false, true, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
+                         ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
+                         acc4, accumulate, units, ucount, uhint, (int)gt->units_cap);                            \
+    else                                                                                                         \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, 2, false, false, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
+                         ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
+                         acc4, accumulate);                                                                      \
+  } while (0)
+    if (guard) NBH_CELL_LAUNCH_F(true); else NBH_CELL_LAUNCH_F(false);
+#undef NBH_CELL_LAUNCH_F
+  }
   else                { if (guard) NBH_CELL_LAUNCH(true, 2); else NBH_CELL_LAUNCH(false, 2); }
 #undef NBH_CELL_LAUNCH
   NBH_LAUNCH_CHECK();
@@ -1449,29 +1565,47 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   // is denser): sphere of 10,000 in a 21^3 grid, rho 1.1, cutoff 2 > cell: 0.050 vs 0.018 ms; 100,000 bodies,
   // rho 10.8, cutoff 2: 0.86 vs 0.10 ms (the cell-run kernel's |cx_j - cx_i| test); rho 1.5 / 1.9: 0.079 /
   // 0.78 vs 0.069 / 0.47 ms.  Uniform box at rho 0.9: 0.16 (cell runs) vs 0.28 ms.
-  // ... and with the unit list the wave-per-cell kernel skips empty cells and spreads crowded ones, so what counts
-  // is the occupancy of the OCCUPIED cells and whether any cell is crowded (both known from the previous call): a box
-  // that has expanded and clumped (mean 0.2 bodies per cell, cells of 300 beside a majority of empty ones) runs 3.5 ms
-  // with it against 4.9 ms with the cell-run kernel; an evenly sparse box stays with the cell-run kernel.
-  const bool stats = g->lb_valid && g->use_units && g->h_unit_hint_dev;
-  const int seen_units = stats ? g->h_unit_hint[0] : 0, seen_crowd = stats ? g->h_unit_hint[1] : 0;
+  // Which kernel runs is a function of the INPUT alone (body count, grid, cutoff -- and, below one body per cell, the
+  // occupancy of the grid just built): kernels of different shapes sum in different orders, and a choice that hung on
+  // statistics arriving asynchronously from earlier calls would make the bits depend on timing.  (Between the cell
+  // range and the unit list of ONE shape the previous call's statistics do decide: those two are bit-identical.)
+  //   >= 1 body per cell (0.5 when cutoff > cell): wave per cell, 1 / 2 bodies per lane below / from 8 per cell, the
+  //   filtered form from 40 per cell;
+  //   below that, with start arrays (<= 16 cells per body): the unit list of THIS grid is made and its most crowded
+  //   cell read back (a second poll of mapped host memory, ~10 us in a regime of multi-millisecond steps): crowded
+  //   cells (> 64 bodies: a box that has expanded and clumped -- mean 0.2 bodies per cell, cells of 300 beside a
+  //   majority of empty ones) take the wave-per-cell kernel over that list (3.5 ms against 4.9 ms), an evenly sparse
+  //   grid takes the cell-run kernel (0.16 against 0.26 ms at 0.9 bodies per cell).
+  int* prebuilt = nullptr;
   if (kern == 0) {
-    const double rho_occ = seen_units > 0 ? (double)n / (double)seen_units : rho;
-    if (!g->lb_valid || (seen_crowd <= 64 && rho < (strict ? 0.5 : 1.0))) kern = 1;
-    else kern = rho_occ < 8.0 ? 2 : 3;
+    if (!g->lb_valid) {
+      kern = 1;
+    } else if (rho >= (strict ? 0.5 : 1.0)) {
+      kern = rho < 8.0 ? 2 : (rho < kFilterFrom ? 3 : 6);
+    } else if (g->use_units && g->h_unit_hint_dev && g->lb_count < 0x7fffffffLL) {
+      const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
+      if (int rc = make_unit_list(ctx, g, view, g->lb_base, g->lb_base + g->lb_count, 64, &prebuilt)) return rc;
+      const int seq = ++g->stat_seq;
+      hipLaunchKernelGGL(cell_units_export_kernel, dim3(1), dim3(64), 0, ctx->stream, prebuilt, g->h_unit_hint_dev, seq);
+      NBH_LAUNCH_CHECK();
+      const volatile int* word = &g->h_unit_hint[2];
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (*word != seq) {
+        if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) break;
+      }
+      if (*word != seq) NBH_HIP(hipStreamSynchronize(ctx->stream));
+      std::atomic_thread_fence(std::memory_order_acquire);
+      kern = g->h_unit_hint[1] > 64 ? 2 : 1;
+      if (kern == 1) prebuilt = nullptr;
+    } else {
+      kern = 1;
+    }
   }
   if (kern != 1 && g->lb_valid) {
     const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
     return launch_cell_forces(ctx, view, view, gx, gy, gz, g->lb_base, g->lb_base + g->lb_count, kern, guard, cutoff2,
-                              eps2, G, ax, ay, az, acc4, 0, g, 0);
-  }
-  if (stats && g->lb_base + g->lb_count - g->lb_base < 0x7fffffffLL && (g->stat_tick++ & 7) == 0) {
-    // the cell-run kernel it is: every eighth call still looks at the occupancies (clumps form over hundreds of steps)
-    const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
-    int* cur = nullptr;
-    if (int rc = make_unit_list(ctx, g, view, g->lb_base, g->lb_base + g->lb_count, 64, &cur)) return rc;
-    hipLaunchKernelGGL(cell_units_export_kernel, dim3(1), dim3(64), 0, ctx->stream, cur, g->h_unit_hint_dev);
-    NBH_LAUNCH_CHECK();
+                              eps2, G, ax, ay, az, acc4, 0, g, 0, prebuilt);
   }
 #define NBH_HASH_LAUNCH(GD, ST)                                                                   \
   hipLaunchKernelGGL((hash_force_kernel<GD, ST>), grid, dim3(kBlock), 0, ctx->stream, g->d_sorted, \
@@ -1547,7 +1681,7 @@ extern "C" int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* gt, nbody_hip_g
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
   const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
   int kern = gt->tune_kernel;
-  if (kern < 2) kern = rho < 8.0 ? 2 : 3;
+  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < kFilterFrom ? 3 : 6);
   const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
   const CellGridView sv{gs->d_sorted, gs->d_cell_lb, gs->d_idx_b, gs->lb_base, gs->lb_count};
   return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f, cutoff2, eps2, G, nullptr, nullptr,

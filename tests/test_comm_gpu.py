@@ -241,7 +241,9 @@ def test_sharded_hash_virtual_ranks_equal_single_gpu(nb, oracle, ctx, W, n, half
         for ax in "xyz":
             vh = prev["vel_" + ax] + prev["acc_" + ax] * hdt
             assert np.allclose(cur["pos_" + ax], prev["pos_" + ax] + vh * np.float32(dt), rtol=3e-7, atol=1e-6), (step, ax)
-            assert np.allclose(cur["vel_" + ax], vh + cur["acc_" + ax] * hdt, rtol=3e-7, atol=1e-6), (step, ax)
+            # (the kernel forms v + (a_old + a_new) h as add + fma: a few ulps of |v| + |a| h from this two-step form)
+            scale = np.abs(vh) + np.abs(cur["acc_" + ax]) * hdt + 1.0
+            assert np.all(np.abs(cur["vel_" + ax] - (vh + cur["acc_" + ax] * hdt)) <= 4 * 2.0 ** -23 * scale), (step, ax)
         prev = cur
     if W > 1 and n >= 20000:
         assert migrated > 0 and halo > 0

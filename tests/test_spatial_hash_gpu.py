@@ -521,3 +521,42 @@ def test_sparse_clumped_grid_against_the_oracle(nb, oracle, ctx, monkeypatch):
             assert np.all(a[~nz] == 0)
             e = rel_err(a[nz], ref[nz])
             assert np.all(e <= np.maximum(TOL, 3 * U * kappa[nz])), (cell, mode, e.max())
+
+
+# the filtered form of the wave-per-cell kernel (nbody_hip_grid_tuning 6: window entries out of reach of the box of
+# the cell's bodies are left out of LDS) against the oracle on every body: crowded cells (where it is the automatic
+# choice), the clumped box, cutoff > cell, eps = 0, and windows too long for one LDS batch
+@pytest.mark.parametrize("case", ["dense", "clumped", "strict", "guard"])
+def test_filtered_form_of_the_cell_kernel(nb, oracle, ctx, monkeypatch, case):
+    monkeypatch.setenv("NBH_HASH_UNITS", "2" if case == "clumped" else "1")
+    eps, G = 0.05, 1.0
+    if case == "dense":
+        n, cell, cutoff = 120000, 2.0, 2.0
+        ic = nb.ic.uniform_box(n, seed=21, lo=-10.0, hi=10.0)          # 15 bodies per unit volume = 120 per cell
+    elif case == "clumped":
+        n, cell, cutoff = 60000, 1.0, 1.0
+        ic = _clumpy_box(nb, n, 6)
+    elif case == "strict":
+        n, cell, cutoff = 80000, 1.0, 1.6
+        ic = nb.ic.uniform_box(n, seed=22, lo=-5.0, hi=5.0, min_mass=0.5, max_mass=1.5)   # 80 per cell, long windows
+    else:
+        n, cell, cutoff, eps = 30000, 1.0, 1.0, 0.0
+        ic = nb.ic.uniform_box(n, seed=23, lo=-3.0, hi=3.0)             # eps = 0: the guarded instantiation, 140 per cell
+    ref, gold, kappa = oracle.spatial_hash_forces_cond(ic["pos_x"], ic["pos_y"], ic["pos_z"], ic["mass"], G,
+                                                       float(np.float32(eps) ** 2), cell, cutoff)
+    d, _ = to_device(nb, ic)
+    calc = nb.SpatialHashCalculator(cell, cutoff)
+    calc.setSofteningParameter(eps)
+    calc.computeForces(d)
+    auto = acc_of(d)
+    calc.getGrid().tuning(6)
+    calc.computeForces(d)
+    calc.computeForces(d)
+    a = acc_of(d)
+    assert np.all(np.isfinite(a))
+    nz = np.linalg.norm(ref, axis=1) > 0
+    assert np.all(a[~nz] == 0)
+    e = rel_err(a[nz], ref[nz])
+    assert np.all(e <= np.maximum(TOL, 3 * U * kappa[nz])), (case, e.max())
+    if case == "dense":                     # ... where the automatic choice is this form already
+        assert np.array_equal(a, auto)
