@@ -465,13 +465,13 @@ def test_unit_form_of_the_cell_kernel_on_clumped_bodies(nb, oracle, ctx, monkeyp
         calc = nb.SpatialHashCalculator(cell, cutoff)
         calc.setSofteningParameter(eps)
         calc.computeForces(d)                      # (the grid is made here, with the mode of the environment)
-        for kernel in (3, 2):                      # two targets per lane (chunks of 128), one (chunks of 64)
+        for kernel in (3, 2, 6):                   # two targets per lane (chunks of 128), one (chunks of 64), filtered
             calc.getGrid().tuning(kernel)
             calc.computeForces(d)                  # (automatic mode: this call has seen the first one's statistics)
             got[mode, kernel] = acc_of(d)
         counts = np.diff(np.stack(calc.getGrid().copyCellDataToHost()[:2]), axis=0)[0]
         assert counts.max() > 300 and (counts == 0).mean() > 0.15      # chunked cells and empty cells are both there
-    for kernel in (3, 2):
+    for kernel in (3, 2, 6):
         assert np.array_equal(got["2", kernel], got["0", kernel]) and np.array_equal(got["1", kernel], got["0", kernel])
     nz = np.linalg.norm(ref, axis=1) > 0
     a = got["2", 3]
