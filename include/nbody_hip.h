@@ -299,6 +299,17 @@ NBODY_HIP_API int nbody_hip_slab_partition(nbody_hip_ctx* ctx, const nbody_float
                                            const nbody_float4* acc, const int* gid, size_t n, const float* gbox_dev,
                                            float cell_size, int world, int rank, int hist_cap, float* rows_out,
                                            int* holes_out, int* send_matrix_dev, int* hist_dev, int* info_dev);
+/* The same with the ranks' slabs bounded by PHYSICAL z coordinates: z_cuts = world - 1 ascending HOST floats (NULL:
+ * equal layer counts, as above); the owner of a layer is the number of cuts at or below the layer's centre,
+ * nbody_hip_slab_layer_owner -- the same arithmetic on the device and on the host, so that every rank's host can
+ * derive the ranks' layer ranges.  A host that balances the slabs by body count picks the cuts from the (all-reduced)
+ * layer histogram of the previous evaluation. */
+NBODY_HIP_API int nbody_hip_slab_partition_cuts(nbody_hip_ctx* ctx, const nbody_float4* posm, const nbody_float4* vel,
+                                                const nbody_float4* acc, const int* gid, size_t count,
+                                                const float* gbox_device, float cell_size, int world, int rank,
+                                                int hist_cap, float* rows_out, int* holes_out, int* send_matrix_device,
+                                                int* hist_device, int* info_device, const float* z_cuts);
+NBODY_HIP_API int nbody_hip_slab_layer_owner(int layer, float lo_z, float cell_size, int world, const float* z_cuts);
 /* After the exchange: n_old bodies (arrays with room for n_old - n_holes + n_arrivals) of which the slots
  * holes[0..n_holes) (ascending, as written by the partition) are vacant, and n_arrivals rows received from
  * the other ranks -> the n_old - n_holes + n_arrivals bodies of the rank, contiguous from slot 0: arrivals go

@@ -121,6 +121,9 @@ PROTOTYPES = {
                                                     C.c_int]),
     "nbody_hip_slab_partition": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_int, C.c_int, C.c_int,
                                            _P, _P, _P, _P, _P]),
+    "nbody_hip_slab_partition_cuts": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_int, C.c_int, C.c_int,
+                                                _P, _P, _P, _P, _P, _P]),
+    "nbody_hip_slab_layer_owner": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_int, _P]),
     "nbody_hip_slab_fill": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P]),
     "nbody_hip_bbox_packed": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "nbody_hip_drift_bbox_packed": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float, _P, _P]),

@@ -29,6 +29,7 @@
 // peer of the same process may still read it.
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -132,6 +133,11 @@ struct nbody_hip_sharded_hash {
   std::vector<HShard> sh;
   HShard* by_rank[NBODY_HIP_MAX_RANKS] = {};
   bool have_state = false;
+  // slab boundaries: W - 1 physical z coordinates (nbody_hip_slab_partition_cuts), chosen from the layer histogram so
+  // that the slabs hold about the same number of bodies; empty: equal layer counts (NBH_SLAB_BALANCE=0, or before the
+  // first state)
+  std::vector<float> zcuts;
+  bool balance = true;
   // diagnostics of the last evaluation
   int two_grid = 1;
   unsigned long long migrated = 0, halo_bodies = 0;
@@ -177,6 +183,10 @@ extern "C" int nbody_hip_sharded_hash_create(nbody_hip_comm* comm, size_t n, flo
   s->n_total = n;
   s->W = comm->world;
   s->G = G; s->eps = eps; s->cell = cell_size; s->cutoff = cutoff;
+  {
+    const char* env = std::getenv("NBH_SLAB_BALANCE");
+    s->balance = !(env && env[0] == '0');
+  }
   const int W = s->W;
   const size_t nstats = (size_t)W * W + kHistCap;
   s->sh.resize(comm->local.size());
@@ -230,11 +240,48 @@ static void grid_from_box(const float raw[6], float cell, float bounds[6], int d
     dims[a] = (cells < 1.0e9f && cells >= 0.0f) ? (int)cells + 1 : 0x40000000;
   }
 }
-static int layer_owner(int z, int gz, int W) {  // rank r owns [r gz / W, (r + 1) gz / W)
+static int layer_owner_equal(int z, int gz, int W) {  // rank r owns [r gz / W, (r + 1) gz / W)
   int r = (int)(((long long)(z + 1) * W - 1) / gz);
   while (r > 0 && (long long)r * gz / W > z) r--;
   while (r + 1 < W && (long long)(r + 1) * gz / W <= z) r++;
   return r;
+}
+// owner of every layer of a grid and the ranks' layer ranges, exactly as the partition pass on the device assigns them
+struct SlabMap {
+  std::vector<int> owner;       // [gz]
+  int lo[NBODY_HIP_MAX_RANKS], hi[NBODY_HIP_MAX_RANKS];
+};
+static SlabMap slab_map(const nbody_hip_sharded_hash* s, float lo_z, int gz) {
+  SlabMap m;
+  const int W = s->W;
+  m.owner.resize((size_t)gz);
+  for (int r = 0; r < W; r++) m.lo[r] = m.hi[r] = 0;
+  for (int z = 0; z < gz; z++)
+    m.owner[(size_t)z] = s->zcuts.empty() ? layer_owner_equal(z, gz, W)
+                                           : nbody_hip_slab_layer_owner(z, lo_z, s->cell, W, s->zcuts.data());
+  for (int r = 0, z = 0; r < W; r++) {  // owners ascend with z: a rank's layers are contiguous
+    while (z < gz && m.owner[(size_t)z] < r) z++;
+    m.lo[r] = z;
+    while (z < gz && m.owner[(size_t)z] == r) z++;
+    m.hi[r] = z;
+  }
+  return m;
+}
+// cuts that give every rank about n / W bodies, from the bodies per layer of a grid with lower bound lo_z: the k-th cut is
+// the lower edge of the first layer at which the running count reaches k n / W
+static void balanced_cuts(nbody_hip_sharded_hash* s, const int* hist, int gz, float lo_z, size_t n) {
+  const int W = s->W;
+  s->zcuts.assign((size_t)(W > 1 ? W - 1 : 0), 0.f);
+  long long run = 0;
+  int z = 0;
+  for (int k = 1; k < W; k++) {
+    const long long want = (long long)((double)n * k / W);
+    while (z < gz && run + hist[z] <= want) run += hist[z++];
+    // layer z holds the body that crosses k n / W: it goes to the side that leaves the smaller error
+    int b = z;
+    if (z < gz && (want - run) * 2 > hist[z]) b = z + 1;
+    s->zcuts[(size_t)(k - 1)] = lo_z + (float)b * s->cell;
+  }
 }
 
 static int body_arrays_reserve(HShard& x, size_t need) {
@@ -280,13 +327,23 @@ extern "C" int nbody_hip_sharded_hash_set_state(nbody_hip_sharded_hash* s, const
   grid_from_box(raw, s->cell, bounds, dims);
   if ((long long)dims[0] * dims[1] * dims[2] > 100000000LL || dims[2] > kHistCap)
     return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
+  s->zcuts.clear();
+  if (s->balance && s->W > 1) {
+    std::vector<int> hist((size_t)dims[2], 0);
+    for (size_t i = 0; i < n; i++) {
+      int cz = (int)floorf((z[i] - bounds[2]) / s->cell);
+      hist[(size_t)(cz < 0 ? 0 : (cz > dims[2] - 1 ? dims[2] - 1 : cz))]++;
+    }
+    balanced_cuts(s, hist.data(), dims[2], bounds[2], n);
+  }
+  const SlabMap map0 = slab_map(s, bounds[2], dims[2]);
   for (auto& sh : s->sh) {
     std::vector<float4> p, v;
     std::vector<int> id;
     for (size_t i = 0; i < n; i++) {
       int cz = (int)floorf((z[i] - bounds[2]) / s->cell);
       cz = cz < 0 ? 0 : (cz > dims[2] - 1 ? dims[2] - 1 : cz);
-      if (layer_owner(cz, dims[2], s->W) != sh.rank) continue;
+      if (map0.owner[(size_t)cz] != sh.rank) continue;
       p.push_back(make_float4(x[i], y[i], z[i], mass[i]));
       v.push_back(vx ? make_float4(vx[i], vy[i], vz[i], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
       id.push_back((int)i);
@@ -366,9 +423,10 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
       NBH_HIP(hipMalloc(reinterpret_cast<void**>(&x.holes), cap * sizeof(int)));
       x.part_cap = cap;
     }
-    if (int rc = nbody_hip_slab_partition(x.ctx, reinterpret_cast<nbody_float4*>(x.posm), reinterpret_cast<nbody_float4*>(x.vel),
-                                          reinterpret_cast<nbody_float4*>(x.acc), x.gid, x.n, x.gbox, s->cell, W, x.rank, kHistCap,
-                                          x.rows, x.holes, x.stats, x.stats + (size_t)W * W, x.info))
+    if (int rc = nbody_hip_slab_partition_cuts(x.ctx, reinterpret_cast<nbody_float4*>(x.posm), reinterpret_cast<nbody_float4*>(x.vel),
+                                               reinterpret_cast<nbody_float4*>(x.acc), x.gid, x.n, x.gbox, s->cell, W, x.rank,
+                                               kHistCap, x.rows, x.holes, x.stats, x.stats + (size_t)W * W, x.info,
+                                               s->zcuts.empty() ? nullptr : s->zcuts.data()))
       return rc;
     NBH_HIP(hipEventRecord(x.ev_b, x.compute));
   }
@@ -415,6 +473,26 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
   const int* M = f.h_stats;                    // M[src * W + dst]
   const int* hist = f.h_stats + (size_t)W * W; // bodies per layer, all ranks
   const long long layer_cells = (long long)gx * gy;
+  const SlabMap map = slab_map(s, bounds[2], gz);  // (with the cuts the partition pass just used)
+  if (s->balance && W > 1) {
+    // cuts for the NEXT evaluation, from this evaluation's histogram (the same on every rank): adopted when they would
+    // take 5 % off the largest slab (a moved cut sends a layer of bodies to another rank: not for every wobble)
+    long long cur_max = 0, cand_max = 0;
+    for (int r = 0; r < W; r++) {
+      long long c = 0;
+      for (int z = map.lo[r]; z < map.hi[r]; z++) c += hist[z];
+      cur_max = c > cur_max ? c : cur_max;
+    }
+    const std::vector<float> old = s->zcuts;
+    balanced_cuts(s, hist, gz, bounds[2], s->n_total);
+    const SlabMap cand = slab_map(s, bounds[2], gz);
+    for (int r = 0; r < W; r++) {
+      long long c = 0;
+      for (int z = cand.lo[r]; z < cand.hi[r]; z++) c += hist[z];
+      cand_max = c > cand_max ? c : cand_max;
+    }
+    if (!(cand_max * 100 < cur_max * 95)) s->zcuts = old;
+  }
   s->migrated = 0;
   s->halo_bodies = 0;
   // -- 5: migration ---------------------------------------------------------------------------------------------------
@@ -495,19 +573,19 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
     HShard& x = s->sh[k];
     Plan& pl = plan[k];
     const int r = x.rank;
-    pl.z_lo = (int)((long long)r * gz / W);
-    pl.z_hi = (int)((long long)(r + 1) * gz / W);
+    pl.z_lo = map.lo[r];
+    pl.z_hi = map.hi[r];
     pl.lower = pl.upper = -1;
     x.n_head = x.n_tail = x.n_halo = 0;
     size_t in_lower = 0, in_upper = 0;
     if (W > 1 && pl.z_hi > pl.z_lo) {
       if (pl.z_lo > 0) {
-        pl.lower = layer_owner(pl.z_lo - 1, gz, W);
+        pl.lower = map.owner[(size_t)(pl.z_lo - 1)];
         x.n_head = (size_t)hist[pl.z_lo];
         in_lower = (size_t)hist[pl.z_lo - 1];
       }
       if (pl.z_hi < gz) {
-        pl.upper = layer_owner(pl.z_hi, gz, W);
+        pl.upper = map.owner[(size_t)pl.z_hi];
         x.n_tail = (size_t)hist[pl.z_hi - 1];
         in_upper = (size_t)hist[pl.z_hi];
       }
@@ -568,7 +646,7 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
       } else {
         if (x.n_head) {  // my lowest layer is the UPPER halo of the owner of the layer below: behind its lower halo
           HShard* d = s->by_rank[pl.lower];
-          const int dz_lo = (int)((long long)d->rank * gz / W);
+          const int dz_lo = map.lo[d->rank];
           const size_t d_in_lower = dz_lo > 0 ? (size_t)hist[dz_lo - 1] : 0;
           NBH_HIP(hipMemcpyAsync(d->halo_in + d_in_lower, x.halo_out, x.n_head * sizeof(float4), hipMemcpyDeviceToDevice, x.comm));
         }

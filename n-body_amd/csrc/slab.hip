@@ -56,12 +56,28 @@ __host__ __device__ inline int slab_owner(int z, int gz, int world) {
   return (int)((((long long)z + 1) * world - 1) / gz);
 }
 
+// ... or, with cuts (n >= 0): the ranks' slabs are bounded by PHYSICAL z coordinates (chosen by the host so that the
+// slabs hold about the same number of bodies): the owner of layer z is the number of cuts at or below the layer's
+// centre, lo_z + (z + 1/2) cell -- formed with ONE fma on the device and on the host (nbody_hip_slab_layer_owner), so
+// that both sides and all ranks assign every layer alike.  Monotone in z: a rank's layers are contiguous.
+struct SlabCuts {
+  float z[kMaxRanks];
+  int n;  // world - 1 cuts, ascending; < 0: equal layer counts (slab_owner)
+};
+__host__ __device__ inline int slab_owner_cuts(int z, float lo_z, float cell, const SlabCuts& c) {
+  const float zc = fmaf((float)z + 0.5f, cell, lo_z);
+  int r = 0;
+  for (int k = 0; k < c.n; k++) r += c.z[k] <= zc ? 1 : 0;
+  return r;
+}
+
 // block b works on the contiguous chunk [b chunk, (b+1) chunk) in rounds of 256 bodies
 __global__ __launch_bounds__(kBlock) void slab_count_kernel(const float4* __restrict__ posm, int n, int chunk,
                                                             const float* __restrict__ gbox, float cell, int world,
                                                             int hist_cap, unsigned char* __restrict__ dest,
                                                             int* __restrict__ layer_of, int* __restrict__ block_counts,
-                                                            int* __restrict__ hist, int* __restrict__ info) {
+                                                            int* __restrict__ hist, int* __restrict__ info,
+                                                            const SlabCuts cuts) {
   __shared__ int cnt[kMaxRanks];
   __shared__ int lhist[kHistLds];  // the block's own histogram of the first kHistLds layers: a few hundred
                                    // global atomics per block instead of one per body
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void slab_count_kernel(const float4* __rest
     int z = -1, d = -1;
     if (i < hi) {
       z = slab_layer(posm[i].z, g, cell);
-      d = slab_owner(z, g.gz, world);
+      d = cuts.n >= 0 ? slab_owner_cuts(z, g.lo_z, cell, cuts) : slab_owner(z, g.gz, world);
       dest[i] = (unsigned char)d;
       layer_of[i] = z;
       if (z < nh) atomicAdd(&lhist[z], 1);
@@ -235,10 +251,27 @@ __global__ __launch_bounds__(kBlock) void slab_fill_kernel(const float4* __restr
 
 using namespace nbh;
 
+extern "C" int nbody_hip_slab_layer_owner(int layer, float lo_z, float cell_size, int world, const float* z_cuts) {
+  if (!z_cuts || world < 1 || world > kMaxRanks) return -1;
+  SlabCuts c;
+  c.n = world - 1;
+  for (int k = 0; k < c.n; k++) c.z[k] = z_cuts[k];
+  return slab_owner_cuts(layer, lo_z, cell_size, c);
+}
+
 extern "C" int nbody_hip_slab_partition(nbody_hip_ctx* ctx, const nbody_float4* posm, const nbody_float4* vel,
                                         const nbody_float4* acc, const int* gid, size_t n, const float* gbox_dev,
                                         float cell_size, int world, int rank, int hist_cap, float* rows_out,
                                         int* holes_out, int* send_matrix_dev, int* hist_dev, int* info_dev) {
+  return nbody_hip_slab_partition_cuts(ctx, posm, vel, acc, gid, n, gbox_dev, cell_size, world, rank, hist_cap, rows_out,
+                                       holes_out, send_matrix_dev, hist_dev, info_dev, nullptr);
+}
+
+extern "C" int nbody_hip_slab_partition_cuts(nbody_hip_ctx* ctx, const nbody_float4* posm, const nbody_float4* vel,
+                                             const nbody_float4* acc, const int* gid, size_t n, const float* gbox_dev,
+                                             float cell_size, int world, int rank, int hist_cap, float* rows_out,
+                                             int* holes_out, int* send_matrix_dev, int* hist_dev, int* info_dev,
+                                             const float* z_cuts) {
   if (!ctx) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null context");
   if (!gbox_dev || !send_matrix_dev || !hist_dev || !info_dev) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world)
@@ -250,6 +283,15 @@ extern "C" int nbody_hip_slab_partition(nbody_hip_ctx* ctx, const nbody_float4* 
   if (n > 0 && (!posm || !vel || !acc)) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (n > 0 && world > 1 && (!rows_out || !holes_out)) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   NBH_NOT_CAPTURABLE(ctx, "the slab partition");
+  SlabCuts cuts;
+  cuts.n = -1;
+  if (z_cuts) {
+    cuts.n = world - 1;
+    for (int k = 0; k < cuts.n; k++) {
+      if (k > 0 && !(z_cuts[k] >= z_cuts[k - 1])) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "slab cuts must ascend");
+      cuts.z[k] = z_cuts[k];
+    }
+  }
   NBH_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
@@ -277,7 +319,7 @@ extern "C" int nbody_hip_slab_partition(nbody_hip_ctx* ctx, const nbody_float4* 
     NBH_HIP(hipMemsetAsync(hist_dev, 0, (size_t)hist_cap * sizeof(int), st));
   }
   hipLaunchKernelGGL(slab_count_kernel, dim3(nblocks), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(posm), ni,
-                     chunk, gbox_dev, cell_size, world, hist_cap, dest, layer_of, block_counts, hist_dev, info_dev);
+                     chunk, gbox_dev, cell_size, world, hist_cap, dest, layer_of, block_counts, hist_dev, info_dev, cuts);
   NBH_LAUNCH_CHECK();
   hipLaunchKernelGGL(slab_scan_kernel, dim3(world), dim3(64), 0, st, block_counts, nblocks, world, rank, totals,
                      send_matrix_dev);
