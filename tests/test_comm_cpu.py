@@ -82,3 +82,16 @@ def test_comm_entry_points_without_a_device(nb):
         nb.sharded.shard_bounds(10, 2, 2)
     with pytest.raises(nb.DeviceException):
         nb.sharded.Comm.init_all(2)
+
+
+# nbody_hip_slab_layer_owner: the host side of the slab cuts of the sharded spatial hash (the same fma the partition
+# kernel evaluates): owner = cuts at or below the layer's centre; monotone, so a rank's layers are contiguous
+def test_slab_layer_owner_is_the_count_of_cuts_below_the_layer_centre(nb):
+    lib = nb._lib.load()
+    cuts = np.array([-3.25, -3.25, 0.5, 7.0], np.float32)          # 5 ranks, one of them without a layer
+    lo, cell = np.float32(-10.001), np.float32(0.75)
+    owners = [lib.nbody_hip_slab_layer_owner(z, float(lo), float(cell), 5, cuts.ctypes.data) for z in range(40)]
+    want = [int(np.sum(cuts <= np.float32(np.float64(np.float32(z) + np.float32(0.5)) * np.float64(cell) + np.float64(lo))))
+            for z in range(40)]
+    assert owners == want and owners == sorted(owners) and set(owners) == {0, 2, 3, 4}
+    assert lib.nbody_hip_slab_layer_owner(3, 0.0, 1.0, 5, None) == -1
