@@ -370,7 +370,9 @@ def other_roofline(a, nb, ps, torch, workload):
     """SURVEY 8d figures for the force kernel of configs 4 / 5, timed alone with events on the
     stream it runs on (the null stream = torch's current stream)."""
     fc, d = ps.force_calculator_, ps.d_particles_
-    iters = max(1, a.kernel_iters)
+    # (these launches are ~1 ms: 30 at least, so that the walk's cost-ordered schedule -- fed by the previous walk -- has
+    # settled as it has inside a run of steps; the first few walks after a pause are up to 10 % slower)
+    iters = max(30, a.kernel_iters)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if workload == "bh":
         tree = fc.getTree()
@@ -378,7 +380,8 @@ def other_roofline(a, nb, ps, torch, workload):
     else:
         grid = fc.getGrid()
         run = lambda: grid.computeForces(d, fc.cutoff_radius_, fc.G_, fc.softening_eps_)  # noqa: E731
-    run()
+    for _ in range(5):
+        run()
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
