@@ -664,6 +664,9 @@ def main():
                            f"{'true' if det else 'false'}>"), "launch_ms": ms_g, "achieved": ach_g,
                 "frac": ach_g / PEAK_FP32_VALU_TFLOPS, "pair_interactions_per_s_kernel": float(n) * n / (ms_g * 1e-3),
                 "note": "same positions, masses multiplied by U[0.75, 1.25)"}
+            if clock:  # (the clock sampled beside the timed steps: this launch runs at the same power limit)
+                out["roofline"]["general_mass"]["frac_at_sustained_clock"] = \
+                    ach_g / PEAK_FP32_VALU_TFLOPS * 2400.0 / clock["sclk_mhz_median"]
             del pg
         del p
     if not sharded and not a.no_extra and a.n == (1 << 20):
