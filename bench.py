@@ -57,14 +57,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--atomics", action="store_true",
                     help="Direct: fp64 atomics instead of the default slot planes + fixed-order sums (not bitwise "
-                         "reproducible; 0.2 % / 3.8 % faster for equal / general masses)")
+                         "reproducible, and slower: 190 against 175 ms per step for general masses at N = 2^20, "
+                         "profiles/r03_direct_det_probe.txt; kept for A/B runs and for sizes whose slot planes do "
+                         "not fit the budget)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the Barnes-Hut / spatial-hash / general-mass objects appended to the default run")
     ap.add_argument("--workload", choices=["direct", "hash", "bh"], default="direct",
                     help="direct = the headline metric (default); hash = BASELINE config 5 (N=4,194,304 "
                          "uniform box, spatial hash, z-slab shards + halo exchange); bh = config 4 "
                          "(N=1,048,576 two-galaxy, Barnes-Hut theta 0.5, one GPU).  hash/bh report steps/s")
-    ap.add_argument("--no-clock", action="store_true", help="do not sample rocm-smi beside the timed steps")
+    ap.add_argument("--no-clock", action="store_true", help="do not sample the engine clock / package power (sysfs) beside the timed steps")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU (RCCL) code path even with one rank (rehearsal)")
     ap.add_argument("--sharded-host", choices=["cabi", "torch"], default="cabi",
@@ -95,13 +97,13 @@ def cpu_share():
     return max(1, n)
 
 
-def cpu_baseline(ic, eps, seconds):
-    """Times the oracle (kind "port": the reference has no CPU force path, SURVEY.md fact 1) on a
-    bounded sample: T targets spread over the index range x all N sources, fp32 sequential sum."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_bind
-    lib = None
-    # rebuild the timing build for THIS host's cores when a compiler is around
+_NATIVE_ORACLE = None  # path of the -march=native timing build (prepare_cpu_oracle), or None: the prebuilt library
+
+
+def prepare_cpu_oracle():
+    """Rebuilds the oracle's timing build for THIS host's cores (gcc -O3 -march=native -fopenmp).  Called at the very
+    start of main(), BEFORE anything initialises the GPU: a process that holds the GPU starts no child program."""
+    global _NATIVE_ORACLE
     try:
         tmp = tempfile.mkdtemp(prefix="nbody_oracle_")
         so = os.path.join(tmp, "libnbody_oracle_native.so")
@@ -109,8 +111,22 @@ def cpu_baseline(ic, eps, seconds):
                                "-fno-fast-math", "-fvisibility=hidden", "-shared", "-o", so,
                                os.path.join(ROOT, "oracle", "nbody_oracle.c"), "-lm"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        lib = oracle_bind.Oracle(so)
+        _NATIVE_ORACLE = so
     except Exception:
+        _NATIVE_ORACLE = None
+
+
+def cpu_baseline(ic, eps, seconds):
+    """Times the oracle (kind "port": the reference has no CPU force path, SURVEY.md fact 1) on a
+    bounded sample: T targets spread over the index range x all N sources, fp32 sequential sum."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind
+    lib = None
+    try:  # the timing build made for this host's cores before the GPU was touched, else the prebuilt library
+        lib = oracle_bind.Oracle(_NATIVE_ORACLE) if _NATIVE_ORACLE else None
+    except Exception:
+        lib = None
+    if lib is None:
         lib = oracle_bind.load(fast=True)
     n = ic["pos_x"].size
     eps2 = float(np.float32(eps) * np.float32(eps))
@@ -165,32 +181,62 @@ def read_pmc_traffic():
 
 
 class ClockSampler:
-    """Engine clock and package power of the GPU WHILE the timed region runs (rocm-smi from a host thread every ~0.4 s;
-    nothing touches the GPU's queues).  The Direct kernel keeps every VALU busy and runs into the 1,400 W package limit:
-    the sustained clock is 2.30-2.40 GHz depending on the box, which is the box-to-box spread of the step time
-    (DESIGN.md 6).  `roofline.clock` reports it and the roofline fraction re-priced at the clock that was actually there."""
+    """Engine clock and package power of the GPU WHILE the timed region runs, read from sysfs by a host thread every
+    ~0.1 s (pp_dpm_sclk / hwmon freq1_input and power1_average of the PCI device torch reports for cuda:current; nothing
+    touches the GPU's queues and NO child process is started: a process that has initialised the GPU must not spawn
+    `rocm-smi`, a `#!/usr/bin/env python3` script, least of all under rocprofv3's preloaded tool library).  The Direct
+    kernel keeps every VALU busy and runs into the 1,400 W package limit: the sustained clock is 2.30-2.40 GHz depending
+    on the box, which is the box-to-box spread of the step time.  `roofline.clock` reports it and the
+    roofline fraction re-priced at the clock that was actually there.  No readable sysfs node: no clock record."""
 
-    def __init__(self):
+    def __init__(self, device_index=0):
         import threading
         self._stop = threading.Event()
         self.samples = []
+        self.src = self.sysfs_sources(device_index)
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     @staticmethod
-    def read():
-        import subprocess
+    def under_profiler():
+        env = os.environ
+        return any("rocprof" in env.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+
+    @staticmethod
+    def sysfs_sources(device_index=0):
+        """sysfs files of the GPU torch calls cuda:<device_index> (matched by PCI address; card0 need not be it)."""
+        import glob
         try:
-            r = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5)
-            card = next(iter(json.loads(r.stdout).values()))
-            rec = {}
-            for k, v in card.items():
-                if "sclk clock speed" in k.lower():
-                    rec["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
-                elif "power" in k.lower():
-                    rec["power_w"] = float(v)
-            return rec if "sclk_mhz" in rec else None
-        except Exception:  # no rocm-smi, no permission, another output format: the record simply has no clock
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            return {}
+        base = os.path.join("/sys/bus/pci/devices", addr)
+        out = {}
+        if os.path.exists(os.path.join(base, "pp_dpm_sclk")):
+            out["sclk"] = os.path.join(base, "pp_dpm_sclk")
+        for h in sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*"))):
+            for name in ("power1_average", "power1_input"):
+                if "power" not in out and os.path.exists(os.path.join(h, name)):
+                    out["power"] = os.path.join(h, name)
+            if os.path.exists(os.path.join(h, "freq1_input")):
+                out["freq"] = os.path.join(h, "freq1_input")
+        return out if ("sclk" in out or "freq" in out) else {}
+
+    def read(self):
+        rec = {}
+        try:
+            if "freq" in self.src:
+                rec["sclk_mhz"] = int(open(self.src["freq"]).read()) / 1e6
+            else:
+                for line in open(self.src["sclk"]):
+                    if "*" in line:
+                        rec["sclk_mhz"] = float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+            if "power" in self.src:
+                rec["power_w"] = int(open(self.src["power"]).read()) / 1e6
+        except Exception:  # unreadable node, another format: the record simply has no clock
             return None
+        return rec if "sclk_mhz" in rec else None
 
     def _run(self):
         while not self._stop.is_set():
@@ -200,12 +246,14 @@ class ClockSampler:
             self._stop.wait(0.1)
 
     def start(self):
-        self._thread.start()
+        if self.src:
+            self._thread.start()
         return self
 
     def stop(self):
         self._stop.set()
-        self._thread.join(timeout=10)
+        if self._thread.is_alive():
+            self._thread.join(timeout=10)
         busy = [r for r in self.samples if r.get("power_w", 0.0) > 600.0] or self.samples
         if not busy:
             return None
@@ -213,7 +261,8 @@ class ClockSampler:
         pw = [r.get("power_w", 0.0) for r in busy]
         return {"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
                 "power_w_mean": sum(pw) / len(pw), "samples": len(busy),
-                "source": "rocm-smi -c -P beside the timed steps (samples above 600 W)"}
+                "source": "sysfs (" + ", ".join(sorted(os.path.basename(v) for v in self.src.values()))
+                          + ") beside the timed steps (samples above 600 W)"}
 
 
 def run_other_workload(a, nb, ctx, world, rank, sharded, dist, torch, workload=None, n_bodies=None,
@@ -429,6 +478,9 @@ def main():
     # communicator comes up, so everything else written to fd 1 is sent to stderr instead
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if (int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+            and not a.no_cpu_baseline and not ClockSampler.under_profiler()):
+        prepare_cpu_oracle()  # the only child process of a run, started before the GPU is initialised
     import torch
     import torch.distributed as dist
 
@@ -564,7 +616,8 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    sampler = ClockSampler().start() if (rank == 0 and world == 1 and not a.no_clock) else None
+    sampler = (ClockSampler(torch.cuda.current_device()).start()
+               if (rank == 0 and world == 1 and not a.no_clock and not ClockSampler.under_profiler()) else None)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()

@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
-"""Direct N^2 kernel at N = 2^20 with 8 / 12 / 16 bodies per lane, each run for ~3 s with rocm-smi sampled beside it:
+"""Direct N^2 kernel at N = 2^20 with 8 / 12 / 16 bodies per lane, each run for ~3 s with the engine clock / package power (sysfs) sampled beside it:
 time per launch, engine clock and package power -- is one of the shapes cheaper in energy (higher sustained clock on a
 power-limited box)?   Usage: python tools/direct_power_probe.py"""
-import json
 import os
-import subprocess
 import sys
 import threading
 import time
@@ -18,19 +16,14 @@ import nbody_amd as nb  # noqa: E402
 from gpu_util import packed  # noqa: E402
 
 
+from bench import ClockSampler  # noqa: E402  (sysfs reader: a process that holds the GPU starts no rocm-smi child)
+
+_clock = ClockSampler(0)
+
+
 def smi():
-    try:
-        r = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5)
-        card = next(iter(json.loads(r.stdout).values()))
-        rec = {}
-        for k, v in card.items():
-            if "sclk clock speed" in k.lower():
-                rec["sclk"] = float(str(v).strip("()").lower().replace("mhz", ""))
-            elif "power" in k.lower():
-                rec["power"] = float(v)
-        return rec
-    except Exception:
-        return {}
+    r = _clock.read() if _clock.src else None
+    return {"sclk": r["sclk_mhz"], "power": r.get("power_w", 0.0)} if r else {}
 
 
 torch.cuda.set_device(0)

@@ -16,7 +16,7 @@ python3 tools/pmc_summarise.py "$OUT/prof_direct" "direct_sym_kernel<16, false, 
 ( cd /tmp && export TMPDIR=/tmp
   for w in bh hash; do
     timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$w" -o run -- \
-        python3 "$REPO/bench.py" --workload $w --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+        python3 "$REPO/bench.py" --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-clock > /dev/null 2>&1
     echo "stats $w rc=$?"
   done )
 bash tools/profile_bh.sh "$OUT/prof_bh" > "$OUT/prof_bh.log" 2>&1; echo "profile bh rc=$?"

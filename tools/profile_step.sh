@@ -16,6 +16,6 @@ for group in "sq1:GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
              "tcc:TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   name=${group%%:*}; counters=${group#*:}
   timeout -k 10 300 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/$name" -o run -- \
-      python3 "$REPO/bench.py" --workload "$WL" --steps 4 --warmup 2 --no-cpu-baseline --no-extra --kernel-iters 1 "$@" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
+      python3 "$REPO/bench.py" --workload "$WL" --steps 4 --warmup 2 --no-cpu-baseline --no-extra --no-clock --kernel-iters 1 "$@" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
   echo "pass $name done"
 done
