@@ -556,6 +556,7 @@ def main():
         if a.sharded_host == "cabi" and a.dist_backend == "nccl" and not a.one_device:
             # the whole step behind the C ABI: RCCL communicator made from C++ (id broadcast over the process
             # group), drift -> all-gather || own x own -> shard pairs -> point-to-point reaction exchange -> kick
+            dog = None
             try:
                 from nbody_amd.sharded import Comm, ShardedDirect
                 comm = Comm.from_torch_distributed(local_rank)
@@ -573,7 +574,10 @@ def main():
                 csys.synchronize()
                 dog.cancel()
                 # the exchange over RCCL with W > 1 cannot be rehearsed on a one-GPU box: before the timed steps, this
-                # rank's rows of a(0) against the one-sided kernel over ALL bodies (N^2 / W pair evaluations, ~30 ms)
+                # rank's rows of a(0) against the one-sided kernel over ALL bodies (N^2 / W pair evaluations, ~30 ms).
+                # Two fp32 evaluations (a deterministic sum against a one-sided running sum), each held to 1e-5 of the
+                # fp64-accumulated oracle by the parity tests: 2e-5 between them -- a reaction block summed twice or dropped
+                # is orders above it.
                 from nbody_amd.sharded import shard_bounds
                 _, lo, hi = shard_bounds(n, world, rank)
                 mine = csys.get_state(gather=False, what=("acc",))
@@ -584,12 +588,22 @@ def main():
                                               float(np.float32(eps) * np.float32(eps))).cpu().numpy()[:, :3]
                 del pall
                 err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
-                if not np.all(np.isfinite(got)) or float(err.max()) > 1e-3:
+                if os.environ.get("NBODY_BENCH_INJECT_SELFCHECK_FAILURE") == "1":  # tests/test_facade_gpu.py: the fallback
+                    err = err + 1.0
+                if not np.all(np.isfinite(got)) or float(err.max()) > 2e-5:
                     raise RuntimeError(f"self-check of the sharded a(0) failed on rank {rank}: max relative error {err.max():.3e}")
                 selfcheck = float(err.max())
             except Exception as e:  # every rank runs the same build: all fall back alike
                 why = f" (C-ABI host unavailable: {type(e).__name__}: {e})"
+                if csys is not None:
+                    try:
+                        csys.close()
+                    except Exception:
+                        pass
                 csys = None
+            finally:
+                if dog is not None:
+                    dog.cancel()  # (also when forces() raised: the fallback below must not be shot by the watchdog)
             ok = torch.tensor([1 if csys is not None else 0], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:

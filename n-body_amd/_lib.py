@@ -5,8 +5,11 @@ present when a context is created, the call raises.  Nothing here imports `oracl
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NBODY_HIP_LIB: another build of the same library (kernel experiments: tools/ build variants into gpurun_out/)
@@ -181,6 +184,47 @@ PROTOTYPES = {
 }
 
 _lib = None
+
+# ---- handle lifetime ------------------------------------------------------------------------
+# Every Python object that owns a C-ABI handle registers here (weakly).  ONE atexit hook closes whatever is still
+# alive, in dependency order (systems before the communicators and contexts they borrow), while the HIP runtime is
+# still up; `__del__` does nothing once the interpreter is finalising.  Without this, an object kept alive by a
+# traceback (a failed test under `pytest -x`) was collected during interpreter finalisation, after the HIP runtime's own
+# static destructors: nbody_hip_tree_destroy -> hipStreamSynchronize on a dead runtime threw std::bad_variant_access
+# inside the runtime and the process ended with SIGABRT (rc 134) instead of the test's exit code.
+# ref dtor this mirrors: src/cuda/force_barnes_hut.cu:212-216 (frees in ~BarnesHutTree, while the CUDA runtime lives).
+CLOSE_ORDER = ("system", "graph", "tree", "grid", "backend", "comm", "context")
+_live = {kind: weakref.WeakSet() for kind in CLOSE_ORDER}
+_hook_registered = False
+_closing_all = False
+
+
+def track(obj, kind: str):
+    """Registers a handle owner (it must have close()) for the exit hook.  Returns obj."""
+    global _hook_registered
+    _live[kind].add(obj)
+    if not _hook_registered:
+        atexit.register(close_all)
+        _hook_registered = True
+    return obj
+
+
+def finalizing() -> bool:
+    """True once `__del__` must not call into the library any more."""
+    return _closing_all or sys.is_finalizing()
+
+
+def close_all():
+    """Closes every live handle owner in dependency order (the atexit hook; also callable by hand)."""
+    global _closing_all
+    for kind in CLOSE_ORDER:
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
+        _live[kind].clear()
+    _closing_all = sys.is_finalizing()
 
 
 def load():

@@ -125,6 +125,7 @@ class Context:
         check(lib.nbody_hip_ctx_create(C.byref(h), self.device, C.c_void_p(stream)))
         self._h = h
         self._lib = lib
+        _lib.track(self, "context")
 
     @property
     def handle(self):
@@ -170,7 +171,8 @@ class Context:
 
     def __del__(self):
         try:
-            self.close()
+            if not _lib.finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 
@@ -180,6 +182,7 @@ class StepGraph:
 
     def __init__(self, ctx: Context, handle):
         self._ctx, self._h = ctx, handle
+        _lib.track(self, "graph")
 
     def launch(self, times: int = 1):
         check(self._ctx._lib.nbody_hip_graph_launch(self._h, int(times)))
@@ -191,7 +194,8 @@ class StepGraph:
 
     def __del__(self):
         try:
-            self.close()
+            if not _lib.finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 
@@ -492,12 +496,18 @@ class SpatialHashGrid:
         check(self.ctx._lib.nbody_hip_grid_create(self.ctx.handle, self.max_particles_,
                                                   self.cell_size_, C.byref(h)))
         self._h = h
+        _lib.track(self, "grid")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            if self.ctx.handle.value:  # (a closed context has taken its stream with it: nothing left to wait for)
+                self.ctx._lib.nbody_hip_grid_destroy(self._h)
+            self._h = C.c_void_p()
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None) is not None and self._h.value:
-                self.ctx._lib.nbody_hip_grid_destroy(self._h)
-                self._h = C.c_void_p()
+            if not _lib.finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 
@@ -640,12 +650,18 @@ class BarnesHutTree:
         self._h = h
         self._count = 0
         self.h_nodes_ = None
+        _lib.track(self, "tree")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            if self.ctx.handle.value:
+                self.ctx._lib.nbody_hip_tree_destroy(self._h)
+            self._h = C.c_void_p()
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None) is not None and self._h.value:
-                self.ctx._lib.nbody_hip_tree_destroy(self._h)
-                self._h = C.c_void_p()
+            if not _lib.finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 

@@ -123,6 +123,7 @@ extern "C" int nbody_hip_ctx_create(nbody_hip_ctx** out, int device, void* strea
 
 extern "C" int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx) {
   if (!ctx) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->posm.release();
@@ -133,7 +134,7 @@ extern "C" int nbody_hip_ctx_destroy(nbody_hip_ctx* ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
   delete ctx;
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 extern "C" int nbody_hip_ctx_set_stream(nbody_hip_ctx* ctx, void* stream) {
@@ -218,12 +219,13 @@ extern "C" int nbody_hip_graph_launch(nbody_hip_graph* g, int times) {
 
 extern "C" int nbody_hip_graph_destroy(nbody_hip_graph* g) {
   if (!g) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->stream);
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 // ---- particle memory -------------------------------------------------------------------

@@ -1514,12 +1514,13 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
 
 extern "C" int nbody_hip_tree_destroy(nbody_hip_tree* g) {
   if (!g) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   (void)hipSetDevice(g->ctx->device);
   if (g->side) (void)hipStreamSynchronize(g->side);
   (void)hipStreamSynchronize(g->ctx->stream);
   g->ctx->alloc_generation++;  // a step graph recorded with this tree is stale now
   tree_release(g);
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 extern "C" int nbody_hip_tree_set_params(nbody_hip_tree* g, int max_depth, int leaf_max) {

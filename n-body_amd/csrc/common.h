@@ -190,6 +190,31 @@ __device__ __forceinline__ float ordered_to_float(unsigned int o) {
   return __uint_as_float(u);
 }
 
+// The *_destroy entry points may be reached while the process is exiting (a host language's garbage collector running
+// after the HIP runtime's own static destructors): a runtime that is gone answers hipErrorDeinitialized -- or throws
+// from inside (std::bad_variant_access out of hipStreamSynchronize was seen once: rc 134).  Then nothing is freed --
+// the address space is about to disappear anyway -- and nothing may propagate across the C ABI.
+inline bool runtime_alive() noexcept {
+  try {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return n > 0;
+  } catch (...) {
+    return false;
+  }
+}
+#define NBH_DESTROY_BEGIN          \
+  if (!nbh::runtime_alive()) return NBODY_HIP_OK; \
+  try {
+#define NBH_DESTROY_END            \
+  } catch (...) {                  \
+  }                                \
+  return NBODY_HIP_OK;
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace nbh

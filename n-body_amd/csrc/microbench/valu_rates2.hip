@@ -124,6 +124,110 @@ __global__ __launch_bounds__(256) void k_p1exact(float* out, unsigned long long*
   EPILOGUE
 }
 
+
+__global__ __launch_bounds__(256) void k_pkfmaf16(float* out, unsigned long long* cyc, float b, float c) {
+  PROLOGUE
+  h2 v[CH];
+  for (int k = 0; k < CH; k++) v[k] = h2{(_Float16)(threadIdx.x * 1e-3f), (_Float16)k};
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(v[k]) : "v"(hb), "v"(hc));
+  }
+  for (int k = 0; k < CH; k++) a[k] += (float)v[k].x + (float)v[k].y;
+  EPILOGUE
+}
+__global__ __launch_bounds__(256) void k_alignbit(float* out, unsigned long long* cyc, float b, float c) {
+  PROLOGUE
+  unsigned m[CH];
+  for (int k = 0; k < CH; k++) m[k] = threadIdx.x + k;
+  const unsigned u = __builtin_bit_cast(unsigned, b);
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(m[k]) : "v"(u));
+  }
+  for (int k = 0; k < CH; k++) a[k] += (float)m[k];
+  EPILOGUE
+}
+__global__ __launch_bounds__(256) void k_dot4c(float* out, unsigned long long* cyc, float b, float c) {
+  PROLOGUE
+  int m[CH];
+  for (int k = 0; k < CH; k++) m[k] = threadIdx.x + k;
+  const int u = __builtin_bit_cast(int, b), w = __builtin_bit_cast(int, c);
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(m[k]) : "v"(u), "v"(w));
+  }
+  for (int k = 0; k < CH; k++) a[k] += (float)m[k];
+  EPILOGUE
+}
+// phase-1 body, int8 form: move (seed = |s|^2) + dot4c + cmp + addc per candidate and target
+__global__ __launch_bounds__(256) void k_p1dot4(float* out, unsigned long long* cyc, float b, float c) {
+  PROLOGUE
+  unsigned m[CH];
+  for (int k = 0; k < CH; k++) m[k] = threadIdx.x;
+  const int u = __builtin_bit_cast(int, b), w = __builtin_bit_cast(int, c);
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      int d;
+      asm volatile("v_mov_b32 %0, %2\n\tv_dot4c_i32_i8 %0, %3, %4\n\t"
+                   "v_cmp_lt_i32 vcc, %0, %4\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                   : "=&v"(d), "+v"(m[k]) : "v"(a[k]), "v"(u), "v"(w) : "vcc");
+    }
+  }
+  for (int k = 0; k < CH; k++) a[k] += (float)m[k];
+  EPILOGUE
+}
+// phase-1 body, packed-f16 form: per candidate and TWO targets  pk_add + 3 pk_fma + alignbit + lshl + alignbit
+__global__ __launch_bounds__(256) void k_p1pkh(float* out, unsigned long long* cyc, float b, float c) {
+  PROLOGUE
+  unsigned m[CH];
+  for (int k = 0; k < CH; k++) m[k] = threadIdx.x;
+  for (int it = 0; it < ITERS; it += 2) {  // (CH chains x 2 targets per body: half the iterations for the same target count)
+#pragma unroll
+    for (int k = 0; k < CH; k += 2) {
+      unsigned r, r2;
+      asm volatile("v_pk_add_f16 %0, %4, %5\n\tv_pk_fma_f16 %0, %4, %5, %0\n\tv_pk_fma_f16 %0, %5, %4, %0\n\t"
+                   "v_pk_fma_f16 %0, %4, %4, %0\n\tv_alignbit_b32 %2, %2, %0, 31\n\tv_lshlrev_b32 %1, 16, %0\n\t"
+                   "v_alignbit_b32 %3, %3, %1, 31"
+                   : "=&v"(r), "=&v"(r2), "+v"(m[k]), "+v"(m[k + 1]) : "v"(hb), "v"(hc));
+      asm volatile("v_pk_add_f16 %0, %4, %5\n\tv_pk_fma_f16 %0, %4, %5, %0\n\tv_pk_fma_f16 %0, %5, %4, %0\n\t"
+                   "v_pk_fma_f16 %0, %4, %4, %0\n\tv_alignbit_b32 %2, %2, %0, 31\n\tv_lshlrev_b32 %1, 16, %0\n\t"
+                   "v_alignbit_b32 %3, %3, %1, 31"
+                   : "=&v"(r), "=&v"(r2), "+v"(m[k]), "+v"(m[k + 1]) : "v"(hc), "v"(hb));
+    }
+  }
+  for (int k = 0; k < CH; k++) a[k] += (float)m[k];
+  EPILOGUE
+}
+// phase-2 body: ffbh + mad (address) + lshr + bfi + 3 sub + mul + 2 fma + add + rsq + 3 mul + cmp + cndmask + 3 fma
+__global__ __launch_bounds__(256) void k_p2(float* out, unsigned long long* cyc, float b, float c) {
+  PROLOGUE
+  unsigned m[CH];
+  for (int k = 0; k < CH; k++) m[k] = 0xffffffffu - threadIdx.x;
+  const unsigned top = 0x80000000u + (unsigned)(b > 10.f);
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      unsigned lz, t, ad;
+      float dx, dy, dz, d2, inv, f;
+      asm volatile("v_ffbh_u32 %0, %3\n\tv_mad_u32_u24 %2, %0, %4, %4\n\tv_lshrrev_b32 %1, %0, %4\n\tv_bfi_b32 %3, %1, 0, %3"
+                   : "=&v"(lz), "=&v"(t), "=&v"(ad), "+v"(m[k]) : "v"(top));
+      asm volatile("v_sub_f32 %0, %9, %10\n\tv_sub_f32 %1, %9, %11\n\tv_sub_f32 %2, %10, %11\n\t"
+                   "v_mul_f32 %3, %0, %0\n\tv_fma_f32 %3, %1, %1, %3\n\tv_fma_f32 %3, %2, %2, %3\n\t"
+                   "v_add_f32 %4, %3, %11\n\tv_rsq_f32 %4, %4\n\tv_mul_f32 %5, %4, %10\n\tv_mul_f32 %4, %4, %4\n\t"
+                   "v_mul_f32 %5, %5, %4\n\tv_cmp_lt_f32 vcc, %3, %11\n\tv_cndmask_b32 %5, 0, %5, vcc\n\t"
+                   "v_fma_f32 %6, %5, %0, %6\n\tv_fma_f32 %7, %5, %1, %7\n\tv_fma_f32 %8, %5, %2, %8"
+                   : "=&v"(dx), "=&v"(dy), "=&v"(dz), "=&v"(d2), "=&v"(inv), "=&v"(f), "+v"(ax), "+v"(ay), "+v"(az)
+                   : "v"(a[k]), "v"(b), "v"(c) : "vcc");
+    }
+  }
+  a[0] += ax + ay + az;
+  for (int k = 0; k < CH; k++) a[k] += (float)m[k];
+  EPILOGUE
+}
+
 typedef void (*kern_t)(float*, unsigned long long*, float, float);
 
 static int run(const char* name, kern_t k, int waves_per_simd, double instr_per_iter, float* out,
@@ -163,6 +267,12 @@ int main() {
     run("p1dot", k_p1dot, w, 5 * CH, out, cyc, h);
     run("p1mix", k_p1mix, w, 5 * CH, out, cyc, h);
     run("p1exact", k_p1exact, w, 8 * CH, out, cyc, h);
+    run("pk_fma_h", k_pkfmaf16, w, CH, out, cyc, h);
+    run("alignbit", k_alignbit, w, CH, out, cyc, h);
+    run("dot4c", k_dot4c, w, CH, out, cyc, h);
+    run("p1dot4", k_p1dot4, w, 4 * CH, out, cyc, h);
+    run("p1pkh", k_p1pkh, w, 3.5 * CH, out, cyc, h);
+    run("p2", k_p2, w, 20 * CH, out, cyc, h);
   }
   return 0;
 }

@@ -250,6 +250,7 @@ extern "C" int nbody_hip_comm_info(const nbody_hip_comm* c, int* world, int* nlo
 
 extern "C" int nbody_hip_comm_destroy(nbody_hip_comm* c) {
   if (!c) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   if (c->transport == NBODY_HIP_TRANSPORT_RCCL) {
     Rccl* api = rccl_load();
     for (auto& m : c->local)
@@ -259,7 +260,7 @@ extern "C" int nbody_hip_comm_destroy(nbody_hip_comm* c) {
       }
   }
   delete c;
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 // ---- the sharded Direct system --------------------------------------------------------------------------------------
@@ -321,9 +322,10 @@ static void shard_release(Shard& s) {
 
 extern "C" int nbody_hip_sharded_direct_destroy(nbody_hip_sharded_direct* s) {
   if (!s) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   for (auto& x : s->sh) shard_release(x);
   delete s;
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 extern "C" int nbody_hip_sharded_direct_create(nbody_hip_comm* comm, size_t n, float G, float eps,

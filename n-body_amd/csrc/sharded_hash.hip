@@ -163,9 +163,10 @@ static void hshard_release(HShard& x) {
 
 extern "C" int nbody_hip_sharded_hash_destroy(nbody_hip_sharded_hash* s) {
   if (!s) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   for (auto& x : s->sh) hshard_release(x);
   delete s;
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 extern "C" int nbody_hip_sharded_hash_create(nbody_hip_comm* comm, size_t n, float G, float eps, float cell_size,

@@ -574,10 +574,41 @@ __global__ __launch_bounds__(kBlock) void hash_force_kernel(
 // ---------------------------------------------------------------------------------------
 constexpr int kWinCap = 512;  // window entries a wave holds in LDS at a time (8 KiB)
 // one window entry against the lane's targets: R = 1 scalar, R even -> R/2 packed pairs
+// The cutoff decision of the packed form WITHOUT compare + select (round 4): with c- the float below cutoff^2, h its ulp
+// and K = c- / h + 1 (an integer <= 2^24: exact),
+//     t = clamp(fma(d2, -1 / h, K))   (v_pk_fma_f32 ... clamp: one packed instruction for both pairs)
+// is exactly 1 for d2 <= c-  <=>  d2 < cutoff^2 (the exact value K - d2 / h is >= 1, and rounding is monotone) and exactly
+// 0 for d2 >= cutoff^2 (exact value <= 0); m t is m or 0 exactly, so the factor (inv (m t)) (inv inv) is bit for bit the
+// selected one.  Two packed instructions instead of two compares and two selects per two pairs: 19 instead of 21
+// instructions per window entry in the loop that is 70 % of the kernel.  (A NaN distance gives t = 0 under DX10 clamp:
+// the pair contributes f = 0 as under the compare.)  Needs 1 / h and K representable: cutoff^2 in [2^-100, 2^100];
+// outside, and when eps^2 < 1e-12, the GUARD instantiation (compare + select, d2 > 0 test) runs.
+struct CutConst {
+  float nbig, k;  // -1 / h, K
+};
+__host__ __device__ inline bool cut_const_ok(float cutoff2) { return cutoff2 >= 7.9e-31f && cutoff2 <= 1.2e30f; }
+__device__ __forceinline__ CutConst cut_const(float cutoff2) {
+  const unsigned cm = __builtin_bit_cast(unsigned, cutoff2) - 1u;   // c-: the float below cutoff^2 (positive, normal)
+  const unsigned e = (cm >> 23) & 255u;                              // c- = 1.m x 2^(e - 127), h = 2^(e - 150)
+  const float big = __builtin_bit_cast(float, (277u - e) << 23);     // 1 / h = 2^(150 - e)
+  CutConst c;
+  c.nbig = -big;
+  c.k = __builtin_bit_cast(float, cm) * big + 1.0f;                  // exact: an integer in (2^23, 2^24]
+  return c;
+}
+
 template <bool GUARD, int R>
 struct CellTargets {
   static constexpr int NP = R / 2;
   f2 px[NP], py[NP], pz[NP], ax[NP], ay[NP], az[NP];
+  f2 nbig, kk;  // the cutoff decision's constants (non-GUARD)
+  __device__ __forceinline__ void set_cut(float cutoff2) {
+    if constexpr (!GUARD) {
+      const CutConst c = cut_const(cutoff2);
+      nbig = (f2)(c.nbig);
+      kk = (f2)(c.k);
+    }
+  }
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int j = 0; j < NP; j++) ax[j] = ay[j] = az[j] = (f2)(0.f);
@@ -594,11 +625,18 @@ struct CellTargets {
       f2 inv;
       inv.x = __builtin_amdgcn_rsqf(de.x);
       inv.y = __builtin_amdgcn_rsqf(de.y);
-      f2 f = (inv * (f2)(s.w)) * (inv * inv);
-      bool ok0 = d2.x < cutoff2, ok1 = d2.y < cutoff2;  // :131, unsoftened distance
-      if (GUARD) { ok0 = ok0 && (d2.x > 0.f); ok1 = ok1 && (d2.y > 0.f); }  // coincident / self: contributes 0
-      f.x = ok0 ? f.x : 0.f;
-      f.y = ok1 ? f.y : 0.f;
+      f2 f;
+      if constexpr (GUARD) {
+        f = (inv * (f2)(s.w)) * (inv * inv);
+        bool ok0 = d2.x < cutoff2, ok1 = d2.y < cutoff2;  // :131, unsoftened distance
+        ok0 = ok0 && (d2.x > 0.f); ok1 = ok1 && (d2.y > 0.f);  // coincident / self: contributes 0
+        f.x = ok0 ? f.x : 0.f;
+        f.y = ok1 ? f.y : 0.f;
+      } else {
+        f2 t;  // 1 where d2 < cutoff^2 (:131, unsoftened distance), else 0
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(d2), "v"(nbig), "v"(kk));
+        f = (inv * (t * (f2)(s.w))) * (inv * inv);
+      }
       ax[j] = __builtin_elementwise_fma(f, dx, ax[j]);
       ay[j] = __builtin_elementwise_fma(f, dy, ay[j]);
       az[j] = __builtin_elementwise_fma(f, dz, az[j]);
@@ -611,6 +649,7 @@ struct CellTargets {
 template <bool GUARD>
 struct CellTargets<GUARD, 1> {
   float px, py, pz, ax, ay, az;
+  __device__ __forceinline__ void set_cut(float) {}
   __device__ __forceinline__ void clear() { ax = ay = az = 0.f; }
   __device__ __forceinline__ void set(int, float x, float y, float z) { px = x; py = y; pz = z; }
   __device__ __forceinline__ void pair(const float4 s, float cutoff2, float eps2) {
@@ -631,7 +670,10 @@ struct CellTargets<GUARD, 1> {
 // loads of cell c+1's window are already in flight (into registers), so that only the first of a
 // wave's cells pays the global-memory latency of its lookups.
 constexpr int kCellsPerWave = 4;
-constexpr double kFilterFrom = 40.0;  // bodies per occupied cell from which the filtered form pays (see FILTER below)
+constexpr double kFilterFrom = 40.0;  // bodies per cell from which the filtered form pays when cutoff > cell (see FILTER below)
+constexpr double kFilterFromInside = 8.0;  // ... and when cutoff <= cell: with the compare-free decision (round 4) the box test
+                                           // pays from the density the two-targets-per-lane form starts at (0.95 against 0.99 ms at
+                                           // 15 per cell, 0.67 against 0.97 ms at cutoff = cell / 2: profiles/r04_hash_kernels.txt)
 
 // A grid as the force kernel sees it.  lb covers the cells [base, base + count] of the (global) grid --
 // the whole grid, or the z-slab a rank holds (sharded path); cells outside hold no bodies of this grid.
@@ -786,6 +828,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       const int sl = (lane * magic) >> 16, slot = lane - sl * T;
       const bool live = sl < S;
       CellTargets<GUARD, R> tg;
+      tg.set_cut(cutoff2);
       double sx[R], sy[R], sz[R];
       [[maybe_unused]] float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -820,8 +863,21 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
         for (int i0 = 0; i0 < iters - 1; i0 += 32) {
           const int i1 = min(i0 + 32, iters - 1);
           tg.clear();
+          if constexpr (R == 1 || GUARD) {
 #pragma unroll 4
-          for (int it = i0; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+            for (int it = i0; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+          } else {
+            // (four entries a round, written out: the packed form's inline-assembly decision keeps the loop unroller away)
+            int it = i0;
+            for (; it + 4 <= i1; it += 4, wp += 4 * S) {
+              const float4 e0 = wp[0], e1 = wp[S], e2 = wp[2 * S], e3 = wp[3 * S];
+              tg.pair(e0, cutoff2, eps2);
+              tg.pair(e1, cutoff2, eps2);
+              tg.pair(e2, cutoff2, eps2);
+              tg.pair(e3, cutoff2, eps2);
+            }
+            for (; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+          }
 #pragma unroll
           for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
         }
@@ -903,8 +959,21 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
         for (int i0 = 0; i0 < iters - 1; i0 += 32) {
           const int i1 = min(i0 + 32, iters - 1);
           tg.clear();
+          if constexpr (R == 1 || GUARD) {
 #pragma unroll 4
-          for (int it = i0; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+            for (int it = i0; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+          } else {
+            // (four entries a round, written out: the packed form's inline-assembly decision keeps the loop unroller away)
+            int it = i0;
+            for (; it + 4 <= i1; it += 4, wp += 4 * S) {
+              const float4 e0 = wp[0], e1 = wp[S], e2 = wp[2 * S], e3 = wp[3 * S];
+              tg.pair(e0, cutoff2, eps2);
+              tg.pair(e1, cutoff2, eps2);
+              tg.pair(e2, cutoff2, eps2);
+              tg.pair(e3, cutoff2, eps2);
+            }
+            for (; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
+          }
 #pragma unroll
           for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
         }
@@ -954,6 +1023,323 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
               acc_x[i] = ox; acc_y[i] = oy; acc_z[i] = oz;
             }
           }
+        }
+      }
+    }
+    if (prefetched && c + 1 < KC) {  // an empty cell (or an empty window): pass the pipeline on
+      __builtin_amdgcn_wave_barrier();
+      NBH_PREFETCH(c + 1)
+    }
+  }
+    if constexpr (!UNITS) break;
+    __builtin_amdgcn_wave_barrier();
+  }
+#undef NBH_SEG0
+#undef NBH_PRE
+#undef NBH_PREFETCH
+}
+
+// ---------------------------------------------------------------------------------------
+// TWO-PHASE form of the wave-per-cell kernel (round 4; nbody_hip_grid_tuning 7, automatic for cutoff <= cell from 8
+// bodies per cell).  Of the 27 rho candidates of a target only (4 pi / 3) / 27 = 15.5 % lie inside the cutoff sphere
+// (cutoff = cell); the one-phase kernel above pays the whole pair evaluation (distance, rsq, factor, three FMAs: ~33 ns
+// per wave step and SIMD) for every one of them, because with 64 lanes on 64 different pairs some lane is always inside.
+// Here the decision and the evaluation are separated:
+//   phase 1: every lane tests ITS candidates against its four targets with the distance chain only (3 sub, mul, 2 fma:
+//            bit for bit the d2 of hash_dist2, so the decision is the reference's, :131) and shifts the outcome into a
+//            32-bit mask per target (v_cmp + v_addc_co: the carry is the new bit) -- 8 VALU per candidate pair, ~8 ns;
+//   phase 2: per target, the lanes walk the set bits of their masks (v_ffbh) and evaluate only those entries, in window
+//            order, with the one-phase kernel's arithmetic (same operations in the same order on the same operands: the
+//            accepted terms are bit-identical; only the grouping of the partial sums differs).
+// Lanes = T target slots x S slices as before, four targets per lane (T = ceil(cnt / 4) <= 4 for a pass of <= 16 targets,
+// S = 64 / T >= 16 slices, so a batch of <= 512 window entries is <= 32 candidates per lane: one mask word per target).
+// A lane's partial sums are fp32 over its <= 32 candidates of a batch, folded into fp64 per batch; the slices are summed
+// in fp64 through LDS in a fixed order: bitwise reproducible.  Cells of more than 16 bodies take further passes over the
+// window, which stays in LDS.  What was measured is in DESIGN.md section 4.4.
+// ---------------------------------------------------------------------------------------
+constexpr int kWinCap2 = 512;                 // window entries per batch (<= 32 per lane at S >= 16 slices)
+constexpr int kR2 = 4;                        // targets per lane
+constexpr int kPass2 = 16;                    // targets per pass
+constexpr int kUnitChunk2 = 64;               // UNITS: bodies per unit (four passes share one window load)
+static_assert(kWinCap2 <= 32 * (64 / (kPass2 / kR2)), "one mask word per target and batch");
+
+// mask <- (mask << 1) | (d < thr): the compare's carry-out is the add's carry-in
+__device__ __forceinline__ void mask_push_lt(unsigned& m, float d, float thr) {
+  asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d), "v"(thr) : "vcc");
+}
+
+// the same for two window entries x four targets in one block (entry 0's bits first: the masks stay in window order)
+// (w0, w1: the entries' fourth components, named as inputs so that the compiler keeps the reads whole: ds_read_b128
+// takes 4 LDS cycles, the b96 it would otherwise choose takes 8)
+__device__ __forceinline__ void mask_push_lt8(unsigned (&m)[4], const float (&d0)[4], const float (&d1)[4], const float (&thr)[4],
+                                              float w0, float w1) {
+  asm volatile(
+      "v_cmp_lt_f32 vcc, %4, %12\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %5, %13\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %6, %14\n\tv_addc_co_u32 %2, vcc, %2, %2, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %7, %15\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %8, %12\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %9, %13\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %10, %14\n\tv_addc_co_u32 %2, vcc, %2, %2, vcc\n\t"
+      "v_cmp_lt_f32 vcc, %11, %15\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3])
+      : "v"(d0[0]), "v"(d0[1]), "v"(d0[2]), "v"(d0[3]), "v"(d1[0]), "v"(d1[1]), "v"(d1[2]), "v"(d1[3]),
+        "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]), "v"(w0), "v"(w1)
+      : "vcc");
+}
+
+template <bool GUARD, bool UNITS>
+__global__ __launch_bounds__(kBlock) void hash_cell_force2_kernel(
+    const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
+    long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
+    float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
+    const int2* __restrict__ units = nullptr, const int* __restrict__ unit_count = nullptr,
+    int* __restrict__ unit_count_host = nullptr, int unit_capacity = 0) {
+  constexpr int KC = kCellsPerWave;
+  constexpr int R = kR2;
+  __shared__ float4 win_all[4][kWinCap2 + 64];  // + 64: the far entries behind a batch, and the reach of a lane's last step
+  __shared__ double red_all[4][R * 64];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float4* win = win_all[w];
+  double* red = red_all[w];
+  const float4* __restrict__ sorted = sgv.sorted;    // window entries
+  const float4* __restrict__ tsorted = tgv.sorted;   // targets
+  const int* __restrict__ idx = tgv.idx;
+  const long long blk = (long long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);  // XCD b mod 8: a contiguous eighth
+  const long long cell0 = cell_first + (blk * 4 + w) * KC;
+  int grp = 0, grp_end = 0, n_units = 0, n_heavy = 0;
+  if constexpr (UNITS) {
+    n_heavy = __builtin_amdgcn_readfirstlane(unit_count[0]);
+    n_units = n_heavy + __builtin_amdgcn_readfirstlane(unit_count[2]);
+    if (unit_count_host && blockIdx.x == 0 && threadIdx.x == 0) {  // chooses and sizes the next launch
+      unit_count_host[0] = n_units;
+      unit_count_host[1] = unit_count[1];
+    }
+    grp = (int)blockIdx.x * 4 + w;
+    grp_end = (n_units + KC - 1) / KC;
+  } else {
+    if (cell0 >= cell_end) return;
+  }
+  for (; !UNITS || grp < grp_end; grp += blocks_per_xcd * 32) {
+  // one round of lookups for all KC cells, lane 16 c + r (see hash_cell_force_kernel)
+  int vseg0 = 0, vlen = 0;
+  {
+    const int c = lane >> 4, r = lane & 15;
+    long long cell = cell0 + c;
+    bool have = c < KC && cell < cell_end;
+    int chunk = 0;
+    if constexpr (UNITS) {
+      const int u = grp * KC + c;
+      have = c < KC && u < n_units;
+      if (have) {
+        const int2 uu = units[u < n_heavy ? u : unit_capacity - 1 - (u - n_heavy)];
+        cell = cell_first + uu.x;
+        chunk = uu.y;
+      }
+    }
+    if (have) {
+      if (r < 9) {
+        const unsigned int c32 = (unsigned int)cell, layer = (unsigned int)gx * (unsigned int)gy;
+        const unsigned int uz = c32 / layer, rem = c32 - uz * layer, uy = rem / (unsigned int)gx;
+        const int cx = (int)(rem - uy * (unsigned int)gx), cy = (int)uy, cz = (int)uz;
+        const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+        if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+          const long long base = ((long long)zz * gy + yy) * gx;
+          vseg0 = sgv.lower(base + max(cx - 1, 0));
+          vlen = sgv.lower(base + min(cx + 2, gx)) - vseg0;
+        }
+      } else if (r < 11) {
+        vseg0 = tgv.lower(cell + (r - 9));
+      } else if (r == 11) {
+        vseg0 = chunk;
+      }
+    }
+  }
+  int vpre;
+  {
+    int incl = vlen;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int up = __shfl_up(incl, off, 16);
+      if ((lane & 15) >= off) incl += up;
+    }
+    vpre = incl - vlen;
+  }
+#define NBH_SEG0(c, r) __builtin_amdgcn_readlane(vseg0, 16 * (c) + (r))
+#define NBH_PRE(c, r) __builtin_amdgcn_readlane(vpre, 16 * (c) + (r))
+  float4 pf[9];  // first 64 entries of each run of the NEXT cell to be evaluated
+#define NBH_PREFETCH(c)                                                                              \
+  _Pragma("unroll") for (int r = 0; r < 9; r++) {                                                    \
+    const int p0 = NBH_PRE(c, r), b = min(NBH_PRE(c, r + 1), kWinCap2);                              \
+    pf[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+    if (p0 < b) pf[r] = sorted[NBH_SEG0(c, r) + (min(p0 + lane, b - 1) - p0)];                       \
+  }
+  NBH_PREFETCH(0)
+
+#pragma unroll
+  for (int c = 0; c < KC; c++) {
+    int t0 = NBH_SEG0(c, 9), t1 = NBH_SEG0(c, 10);
+    if constexpr (UNITS) {  // one chunk of the cell's bodies
+      t0 += NBH_SEG0(c, 11) * kUnitChunk2;
+      t1 = min(t1, t0 + kUnitChunk2);
+    }
+    const int Lw = NBH_PRE(c, 9);
+    bool prefetched = true;   // the registers pf hold batch 0 of this cell
+    bool resident = false;    // LDS holds the whole window (one batch) from an earlier pass
+    for (int tb = t0; tb < t1; tb += kPass2) {
+      const int cnt = min(t1 - tb, kPass2);
+      const int T = (cnt + R - 1) / R;  // target slots: 1..4
+      const int S = 64 / T;             // slices: 64, 32, 21, 16
+      const int magic = (65536 + T - 1) / T;
+      const int sl = (lane * magic) >> 16, slot = lane - sl * T;
+      const bool live = sl < S;
+      float tx[R], ty[R], tz[R], thr[R];
+      double sx[R], sy[R], sz[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        const int k = slot + q * T;
+        const float4 p = tsorted[tb + min(k, cnt - 1)];
+        tx[q] = p.x; ty[q] = p.y; tz[q] = p.z;
+        thr[q] = (live && k < cnt) ? cutoff2 : -1.0f;  // (no d2 is below -1: a slot without a target collects nothing)
+        sx[q] = sy[q] = sz[q] = 0.0;
+      }
+      for (int vb = 0; vb < Lw; vb += kWinCap2) {
+        const int Lb = min(Lw - vb, kWinCap2);
+        if (!resident) {
+          __builtin_amdgcn_wave_barrier();
+          if (prefetched) {
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+              const int p0 = NBH_PRE(c, r), b = min(NBH_PRE(c, r + 1), Lb);
+              if (p0 + lane < b) win[p0 + lane] = pf[r];
+              for (int v = p0 + 64 + lane; v < b; v += 64) win[v] = sorted[NBH_SEG0(c, r) + (v - p0)];
+            }
+            prefetched = false;
+            if (c + 1 < KC) { NBH_PREFETCH(c + 1) }  // in flight while this cell is evaluated
+          } else {
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+              const int p0 = NBH_PRE(c, r), a = max(p0, vb), b = min(NBH_PRE(c, r + 1), vb + Lb);
+              for (int v = a + lane; v < b; v += 64) win[v - vb] = sorted[NBH_SEG0(c, r) + (v - p0)];
+            }
+          }
+          win[Lb + lane] = make_float4(1.0e30f, 0.f, 0.f, 0.f);  // behind the batch: entries no target accepts (d2 overflows to +inf;
+                                                                  // finite, so that a lane without a set bit adds 0 x dx = 0)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          resident = Lw <= kWinCap2;
+        }
+        // ---- phase 1: the distance test of every candidate, one mask bit per candidate and target
+        const int iters = (Lb + S - 1) / S;  // <= 32
+        const float4* wp = win + (live ? sl : 0);
+        unsigned m[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) m[q] = 0u;
+        // Four entries a round, two and two: the LDS reads of one pair are in flight while the other pair is tested.  Reads
+        // past the last step are clamped to it (wave-uniform addresses); their bits are shifted out again below.
+        const int last_it = iters - 1;
+        const int rounds = (iters + 3) >> 2;
+        if (iters > 0) {
+          float4 a0 = wp[0], a1 = wp[min(1, last_it) * S];
+          for (int r = 0; r < rounds; r++) {
+            const int it = 4 * r;
+            const float4 b0 = wp[min(it + 2, last_it) * S], b1 = wp[min(it + 3, last_it) * S];
+            float d0[R], d1[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+              d0[q] = hash_dist2(a0.x - tx[q], a0.y - ty[q], a0.z - tz[q]);   // :131, unsoftened distance
+              d1[q] = hash_dist2(a1.x - tx[q], a1.y - ty[q], a1.z - tz[q]);
+            }
+            mask_push_lt8(m, d0, d1, thr, a0.w, a1.w);
+            a0 = wp[min(it + 4, last_it) * S];
+            a1 = wp[min(it + 5, last_it) * S];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+              d0[q] = hash_dist2(b0.x - tx[q], b0.y - ty[q], b0.z - tz[q]);
+              d1[q] = hash_dist2(b1.x - tx[q], b1.y - ty[q], b1.z - tz[q]);
+            }
+            mask_push_lt8(m, d0, d1, thr, b0.w, b1.w);
+          }
+        }
+        const int extra = 4 * rounds - iters;  // bits of the clamped reads
+        // ---- phase 2: the accepted candidates of each target, oldest bit (first window entry) first
+        const int sh = 32 - iters;
+        const unsigned wbase = live ? (unsigned)sl : 0u;
+        const unsigned last = (unsigned)(iters - 1);
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          unsigned mm = iters > 0 ? ((m[q] >> extra) << sh) : 0u;
+          float ax = 0.f, ay = 0.f, az = 0.f;
+          // (one step ahead: the entry of the next set bit is on its way from LDS while this one is evaluated)
+          bool more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
+          unsigned lz = (unsigned)__builtin_clz(mm | 1u);
+          bool valid = mm != 0u;
+          float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (more) e = win[wbase + __umul24(min(lz, last), (unsigned)S)];
+          mm &= ~(0x80000000u >> lz);
+          while (more) {
+            more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
+            lz = (unsigned)__builtin_clz(mm | 1u);
+            const bool valid2 = mm != 0u;
+            float4 e2 = e;
+            if (more) e2 = win[wbase + __umul24(min(lz, last), (unsigned)S)];
+            mm &= ~(0x80000000u >> lz);
+            const float dx = e.x - tx[q];
+            float dy = e.y - ty[q];
+            asm("" : "+v"(dy));  // (keeps the SLP vectoriser from pairing dy / dz into packed ops that need register moves)
+            const float dz = e.z - tz[q];
+            const float d2 = hash_dist2(dx, dy, dz);
+            const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+            bool ok = valid && (d2 < cutoff2);
+            if (GUARD) ok = ok && (d2 > 0.f);  // coincident / self: contributes 0
+            float mi = e.w * inv;
+            asm("" : "+v"(mi));  // (likewise: no packed multiply of (m inv, inv inv))
+            float f = mi * (inv * inv);
+            f = ok ? f : 0.f;
+            ax = __builtin_fmaf(f, dx, ax);
+            ay = __builtin_fmaf(f, dy, ay);
+            asm("" : "+v"(ay));  // (and no packed FMA of (ay, az))
+            az = __builtin_fmaf(f, dz, az);
+            e = e2;
+            valid = valid2;
+          }
+          sx[q] += (double)ax; sy[q] += (double)ay; sz[q] += (double)az;
+        }
+      }
+      // ---- the sum over the slices, one component at a time (red holds R x 64 doubles): lane 4 k + part sums the
+      // slices part, part + 4, ... of target k = slot + q T, the four parts are added across the quad, and lane
+      // 4 k + comp keeps component comp
+      double res = 0.0;
+      const int kk = lane >> 2, part = lane & 3;
+      const int qk = (kk * magic) >> 16, slotk = kk - qk * T;  // target kk of the pass = (slot slotk, register qk)
+#pragma unroll
+      for (int comp = 0; comp < 3; comp++) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          const double v = comp == 0 ? sx[q] : (comp == 1 ? sy[q] : sz[q]);
+          red[q * 64 + lane] = live ? v : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double v = 0.0;
+        if (kk < cnt)
+          for (int s2 = part; s2 < S; s2 += 4) v += red[qk * 64 + slotk + s2 * T];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        if (part == comp) res = v;
+      }
+      if (kk < cnt) {
+        const int i = idx[tb + kk];
+        const float o = part < 3 ? (float)((double)G * res) : 0.f;
+        if (acc4) {
+          float* dst = reinterpret_cast<float*>(acc4 + i) + part;
+          if (accumulate && part < 3) *dst = *dst + o; else *dst = o;
+        } else if (part < 3) {
+          (part == 0 ? acc_x : (part == 1 ? acc_y : acc_z))[i] = o;
         }
       }
     }
@@ -1057,7 +1443,7 @@ struct nbody_hip_grid {
   long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
   int slab_z0 = 0, slab_nz = 0;         // packed builds: z layers this grid holds (nz <= 0: all)
   int tune_kernel = 0;                 // 0 automatic, 1 cell-run kernel, 2 / 3 / 4 wave-per-cell kernel with R = 1 / 2 / 4,
-                                       // 5 = half-shell TIMING PROBE (not forces)
+                                       // 5 = half-shell TIMING PROBE (not forces), 6 = filtered form, 7 = two-phase form
   bool ranges_valid = false;
   // host mirror of the last build
   GridInfo info{};
@@ -1134,10 +1520,11 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
 
 extern "C" int nbody_hip_grid_destroy(nbody_hip_grid* g) {
   if (!g) return NBODY_HIP_OK;
+  NBH_DESTROY_BEGIN
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->stream);
   grid_release(g);
-  return NBODY_HIP_OK;
+  NBH_DESTROY_END
 }
 
 extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) {
@@ -1149,7 +1536,7 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
 }
 extern "C" int nbody_hip_grid_tuning(nbody_hip_grid* g, int kernel) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
-  if (kernel < 0 || kernel > 6) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..6");
+  if (kernel < 0 || kernel > 7) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..7");
   g->tune_kernel = kernel;
   return NBODY_HIP_OK;
 }
@@ -1473,7 +1860,8 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
   const int* ucount = nullptr;
   int* uhint = nullptr;
   if (can_list) {
-    const int R = kern == 2 ? 1 : (kern == 4 ? 4 : 2);  // (3, 6: two)
+    const int R = (kern == 2 || kern == 7) ? 1 : (kern == 4 ? 4 : 2);  // (3, 6: two; 7: units of kUnitChunk2 = 64 bodies)
+    static_assert(kUnitChunk2 == 64, "the two-phase kernel's units are the 64-body chunks of the one-body-per-lane list");
     const size_t nb = gt->built_count;
     const long long cells = cell_end - cell_first;
     uhint = gt->h_unit_hint_dev ? gt->h_unit_hint_dev + 4 * hint_slot : nullptr;
@@ -1512,7 +1900,21 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
                          acc4, accumulate);                                                                      \
   } while (0)
-  if (kern == 5) {  // timing probe (see the kernel): not forces
+  if (kern == 7) {  // two-phase form: distance masks first, then the accepted candidates only
+#define NBH_CELL2_LAUNCH(GD)                                                                                     \
+  do {                                                                                                           \
+    if (by_units)                                                                                                \
+      hipLaunchKernelGGL((hash_cell_force2_kernel<GD, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,     \
+                         ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
+                         acc4, accumulate, units, ucount, uhint, (int)gt->units_cap);                            \
+    else                                                                                                         \
+      hipLaunchKernelGGL((hash_cell_force2_kernel<GD, false>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,    \
+                         ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
+                         acc4, accumulate);                                                                      \
+  } while (0)
+    if (guard) NBH_CELL2_LAUNCH(true); else NBH_CELL2_LAUNCH(false);
+#undef NBH_CELL2_LAUNCH
+  } else if (kern == 5) {  // timing probe (see the kernel): not forces
     hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, ctx->stream, tv,
                        sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az, acc4, accumulate);
   } else if (kern == 2) { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
@@ -1555,7 +1957,7 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   if (grid.y > 65535u || grid.z > 65535u)
     return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;  // :312-313
-  const bool guard = eps2 < 1e-12f;
+  const bool guard = eps2 < 1e-12f || !cut_const_ok(cutoff2);  // (the general instantiation: compare + select, d2 > 0 test)
   const bool strict = cutoff > g->cell_size;
   // wave-per-cell kernel: needs the cell_lb array; pays from about two bodies per cell
   int kern = g->tune_kernel;
@@ -1581,7 +1983,7 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
     if (!g->lb_valid) {
       kern = 1;
     } else if (rho >= (strict ? 0.5 : 1.0)) {
-      kern = rho < 8.0 ? 2 : (rho < kFilterFrom ? 3 : 6);
+      kern = rho < 8.0 ? 2 : (rho < (strict ? kFilterFrom : kFilterFromInside) ? 3 : 6);
     } else if (g->use_units && g->h_unit_hint_dev && g->lb_count < 0x7fffffffLL) {
       const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
       if (int rc = make_unit_list(ctx, g, view, g->lb_base, g->lb_base + g->lb_count, 64, &prebuilt)) return rc;
@@ -1681,10 +2083,10 @@ extern "C" int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* gt, nbody_hip_g
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
   const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
   int kern = gt->tune_kernel;
-  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < kFilterFrom ? 3 : 6);
+  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < (cutoff > gt->cell_size ? kFilterFrom : kFilterFromInside) ? 3 : 6);
   const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
   const CellGridView sv{gs->d_sorted, gs->d_cell_lb, gs->d_idx_b, gs->lb_base, gs->lb_count};
-  return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f, cutoff2, eps2, G, nullptr, nullptr,
+  return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f || !cut_const_ok(cutoff2), cutoff2, eps2, G, nullptr, nullptr,
                             nullptr, reinterpret_cast<float4*>(acc_out), accumulate ? 1 : 0, gt, accumulate ? 1 : 0);
 }
 

@@ -33,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import check
+from ._lib import finalizing as _lib_finalizing, track as _lib_track
 from .api import Context, direct_forces_pair_packed, direct_forces_packed
 
 
@@ -44,6 +45,7 @@ class HipBackend:
         self.device = ctx.torch_device
         self._grids = {}
         self._tree = None
+        _lib_track(self, "backend")
 
     def close(self):
         """Frees the lazily created grid / tree handles (also run at garbage collection)."""
@@ -58,7 +60,8 @@ class HipBackend:
 
     def __del__(self):
         try:
-            self.close()
+            if not _lib_finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 

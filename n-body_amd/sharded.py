@@ -15,7 +15,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, load
+from ._lib import check, finalizing, load, track
 
 TRANSPORT_P2P, TRANSPORT_RCCL = 0, 1
 MAX_RANKS = 32
@@ -41,6 +41,7 @@ class Comm:
     def __init__(self, handle):
         self._h = handle
         self._lib = load()
+        track(self, "comm")
 
     @staticmethod
     def init_all(ndev: int, devices=None, transport: int = TRANSPORT_P2P) -> "Comm":
@@ -85,7 +86,8 @@ class Comm:
 
     def __del__(self):
         try:
-            self.close()
+            if not finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 
@@ -102,6 +104,7 @@ class ShardedDirect:
         self._lib = load()
         self._h = C.c_void_p()
         check(self._lib.nbody_hip_sharded_direct_create(comm._h, n, G, eps, C.byref(self._h)))
+        track(self, "system")
 
     def set_state(self, ic: dict):
         a = [_f(ic[k]) for k in ("pos_x", "pos_y", "pos_z", "mass")]
@@ -146,12 +149,14 @@ class ShardedDirect:
 
     def close(self):
         if self._h is not None and self._h.value:
-            self._lib.nbody_hip_sharded_direct_destroy(self._h)
+            if self.comm._h is not None and self.comm._h.value:  # (the system borrows the communicator's streams)
+                self._lib.nbody_hip_sharded_direct_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
         try:
-            self.close()
+            if not finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass
 
@@ -164,6 +169,7 @@ class ShardedHash:
         self._lib = load()
         self._h = C.c_void_p()
         check(self._lib.nbody_hip_sharded_hash_create(comm._h, n, G, eps, cell_size, cutoff, C.byref(self._h)))
+        track(self, "system")
 
     def set_state(self, ic: dict):
         a = [_f(ic[k]) for k in ("pos_x", "pos_y", "pos_z", "mass")]
@@ -205,11 +211,13 @@ class ShardedHash:
 
     def close(self):
         if self._h is not None and self._h.value:
-            self._lib.nbody_hip_sharded_hash_destroy(self._h)
+            if self.comm._h is not None and self.comm._h.value:
+                self._lib.nbody_hip_sharded_hash_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
         try:
-            self.close()
+            if not finalizing():  # (else: closed by the exit hook _lib.close_all, or the runtime is going down)
+                self.close()
         except Exception:
             pass

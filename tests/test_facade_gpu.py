@@ -140,6 +140,34 @@ def test_sharded_bench_rehearsal_one_rank(workload, n):
         assert doc["metric"] == "pair_interactions_per_s" and "roofline" in doc
 
 
+# bench.py's safety net for the first real multi-rank run: when the C-ABI host's a(0) fails its self-check (injected
+# here through the environment), every rank falls back to the torch.distributed host, the timed steps run there, and the
+# record says so in config.path; the 180 s watchdog of the failed attempt is cancelled (it would end the run with rc 3)
+def test_sharded_bench_falls_back_when_the_cabi_selfcheck_fails():
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline",
+           "--workload", "direct", "--bodies", "65536", "--kernel-iters", "1"]
+    docs = {}
+    for inject in ("0", "1"):
+        env = dict(os.environ, NBODY_BENCH_INJECT_SELFCHECK_FAILURE=inject)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout
+        docs[inject] = json.loads(lines[0])
+    ok, fell = docs["0"]["config"]["path"], docs["1"]["config"]["path"]
+    assert ok.startswith("C ABI (nbody_hip_sharded_direct_step)") and "max relative error" in ok
+    assert fell.startswith("torch.distributed host") and "self-check of the sharded a(0) failed" in fell
+    assert docs["1"]["value"] > 0 and docs["1"]["steps"] == 2
+
+
 # the N-rank branches of bench.py (shard-pair roofline leg, rank-0-only JSON, max over ranks) with TWO
 # ranks on the one test GPU: gloo transport, everything else as in the driver's N-GPU run
 @pytest.mark.parametrize("workload,n", [("direct", 100000), ("hash", 200000), ("bh", 150000)])

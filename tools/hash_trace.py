@@ -1,4 +1,4 @@
-"""Spatial-hash steps for rocprofv3 (counters or kernel trace): hash_trace.py [N] [steps]"""
+"""Spatial-hash steps for rocprofv3 (counters or kernel trace): hash_trace.py [N] [steps] [force kernel (grid tuning)]"""
 import os
 import sys
 
@@ -18,6 +18,8 @@ fc = nb.SpatialHashCalculator(1.0, 1.0)
 fc.setSofteningParameter(0.01)
 integ = nb.Integrator()
 fc.computeForces(d)
+if len(sys.argv) > 3:
+    fc.getGrid().tuning(int(sys.argv[3]))
 for _ in range(steps):
     integ.integrate(d, fc, 1e-3)
 torch.cuda.synchronize()

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nbody_amd as nb  # noqa: E402
 import oracle_bind  # noqa: E402
-from gpu_util import acc_of, rel_err, to_device  # noqa: E402
+from gpu_util import acc_of, hash_bound, hash_margin, rel_err, to_device  # noqa: E402
 from nbody_amd.sharded import Comm, ShardedHash  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 4
@@ -31,7 +31,6 @@ sysm.set_state(ic)
 sysm.forces()
 worst = 0.0
 orc = oracle_bind.load()
-U = 2.0 ** -24
 for s0 in range(0, steps, every):
     sysm.step(dt, every)
     st = sysm.get_state()
@@ -49,17 +48,16 @@ for s0 in range(0, steps, every):
     nz = np.linalg.norm(a1, axis=1) > 0
     assert np.all(a[~nz] == 0)
     e = rel_err(a[nz], a1[nz])
-    # two fp32 evaluations that sum in different orders: each is within max(1e-5, 3 u kappa) of the oracle (kappa = the
-    # condition number of the body's sum, tests/test_spatial_hash_gpu.py), so they are within twice that of each other
+    # two fp32 evaluations of the same terms grouped differently: the derived condition-aware criterion of
+    # tests/gpu_util.py (kappa = the condition number of the body's sum, from the oracle) -- the one every test uses
     _, _, kappa = orc.spatial_hash_forces_cond(st["pos_x"], st["pos_y"], st["pos_z"], ic["mass"], G,
                                                float(np.float32(eps) ** 2), cell, cutoff)
-    bound = 2 * np.maximum(1e-5, 3 * U * kappa[nz])
+    bound = hash_bound(kappa[nz], "gpu")
     info = sysm.info()
     cs, ce, _, _ = fc.getGrid().copyCellDataToHost()
     worst = max(worst, float(e.max()))
-    print(f"step {s0 + every:5d}: max rel diff sharded vs single GPU {e.max():.2e} (worst against its bound {float((e / bound).max()):.2f}); grid {info['dims']}, two_grid {info['two_grid']}, "
+    print(f"step {s0 + every:5d}: max rel diff sharded vs single GPU {e.max():.2e} (worst against its bound {float((e / bound).max()):.2f}, margin err / (u kappa) {hash_margin(e, kappa[nz]):.2f}); grid {info['dims']}, two_grid {info['two_grid']}, "
           f"migrated last step {info['migrated']}, halo bodies {info['halo_bodies']}, most crowded cell {int((ce - cs).max())}, "
           f"per rank {info['local_counts']}", flush=True)
     assert np.all(e <= bound), (e.max(), float((e / bound).max()))
-    assert np.all(e[kappa[nz] <= 56] < 1e-5)
 print(f"ok: worst {worst:.2e}")
