@@ -35,6 +35,21 @@
  *   reproducible run after run; softening below 1e-6 (eps^2 < 1e-12) takes the one-sided kernel against the
  *   gathered bodies instead (no exchange).
  *
+ * Devices and streams: the entry points of this header walk over the local ranks' devices (hipSetDevice) and restore
+ * the CALLER'S CURRENT DEVICE on every return path (round 4; csrc/common.h DeviceGuard) -- the facade and the
+ * reference's threading model are "current device, null stream" (ref: include/nbody/force_calculator.hpp:8-19), so the
+ * caller's next allocation or null-stream launch lands where it did before the call.  The work itself runs on the
+ * system's own streams (one compute and one comm stream per local rank); the resident calls (forces / step) are
+ * asynchronous and ordered among themselves, nbody_hip_sharded_*_synchronize waits for them.  Only the plugin form
+ * (nbody_hip_sharded_direct_compute_forces) touches caller memory asynchronously: it orders itself against the NULL
+ * stream of the FIRST local rank's device (where `d` must live) at entry and exit, not against any other stream or
+ * device of the caller.
+ *
+ * Limits of the sharded spatial hash (nbody_hip_sharded_hash_*): a grid of at most 1e8 cells like the reference's
+ * (ref: src/cuda/force_spatial_hash.cu:252-254) AND at most 4,096 layers along z (the partition pass histograms the
+ * layers in one workgroup's LDS): taller grids are refused with NBODY_HIP_ERR_RESOURCE, where the single-GPU grid
+ * accepts any shape up to 1e8 cells.  At cell = cutoff that is a box 4,096 cutoffs tall.
+ *
  * Status codes and error text as in nbody_hip.h; RCCL failures are NBODY_HIP_ERR_COMM.
  */
 #ifndef NBODY_HIP_COMM_H

@@ -1399,6 +1399,8 @@ static hipError_t dmalloc(T** p, size_t count) {
 
 // everything whose size depends on the tree shape: keys (32- or 64-bit), the level-major flag / scan
 // arrays, the sort / scan scratch and the node arrays
+static void tree_sort_self_test(hipStream_t st);  // (defined below nbody_hip_tree_create)
+
 static int tree_alloc_nodes(nbody_hip_tree* g) {
   void* ptrs[] = {g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_keys_a, g->d_keys_b, g->d_plane, g->d_rank_off, g->d_last_tmp, g->d_tmp};
@@ -1437,7 +1439,9 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
                                                 static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
                                                 30, g->ctx->stream);
     g->own_sort_from = own_sort_from(kOwnSortFromTree);
-    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && n >= g->own_sort_from) {  // the Onesweep driver of our own
+    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && NBH_BH_OWN_SORT && n >= g->own_sort_from)
+      tree_sort_self_test(g->ctx->stream);  // (once per process: the Onesweep driver against the public sort, onesweep.h)
+    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && onesweep::usable() && n >= g->own_sort_from) {  // the Onesweep driver of our own
       size_t t2 = 0;
       e = onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
           nullptr, t2, static_cast<const unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b),
@@ -1510,6 +1514,73 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
   }
   *out = g;
   return NBODY_HIP_OK;
+}
+
+// Run-time half of the dependency fence of onesweep.h for the tree's instantiation (64-bit Morton keys, index payload):
+// one buffer through the Onesweep driver and through the public rocprim::radix_sort_pairs, every output word compared.
+// Once per process (the first tree that could take the driver).
+static void tree_sort_self_test(hipStream_t st) {
+#if NBH_BH_OWN_SORT && NBH_ONESWEEP_AVAILABLE && NBH_BH_RADIX_BITS > 0
+  static std::atomic<bool> done{false};
+  if (done.exchange(true) || nbh::onesweep::self_test_state().load(std::memory_order_acquire) == 2) return;
+  const size_t n = 200000;
+  const unsigned first_bit = 3, end_bit = 63;  // (a depth-20 build sorts bits 3..62)
+  std::vector<unsigned long long> hk(n);
+  std::vector<int> hv(n);
+  unsigned long long x = 88172645463325252ull;
+  for (size_t i = 0; i < n; i++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    hk[i] = (x >> 1) & ~0xfffffull;  // clustered low digits: many equal keys, so that stability shows
+    hv[i] = (int)i;
+  }
+  unsigned long long *k_in = nullptr, *k_out[2] = {nullptr, nullptr};
+  int *v_in = nullptr, *v_out[2] = {nullptr, nullptr};
+  void* tmp = nullptr;
+  size_t t1 = 0, t2 = 0;
+  bool ran = false, same = false;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&k_in), n * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v_in), n * sizeof(int));
+  for (int v = 0; v < 2 && e == hipSuccess; v++) {
+    e = hipMalloc(reinterpret_cast<void**>(&k_out[v]), n * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v_out[v]), n * sizeof(int));
+  }
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs<SortConfig64>(nullptr, t1, k_in, k_out[1], v_in, v_out[1], n, first_bit, end_bit, st);
+  if (e == hipSuccess) e = onesweep::sort_pairs<NBH_BH_RADIX_BITS>(nullptr, t2, static_cast<const unsigned long long*>(k_in), k_out[0], v_in, v_out[0], n, first_bit, end_bit, st);
+  const size_t tb = t1 > t2 ? t1 : t2;
+  if (e == hipSuccess) e = hipMalloc(&tmp, tb > 0 ? tb : 16);
+  if (e == hipSuccess) e = hipMemcpyAsync(k_in, hk.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(v_in, hv.data(), n * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    size_t b = tb;
+    e = onesweep::sort_pairs<NBH_BH_RADIX_BITS>(tmp, b, static_cast<const unsigned long long*>(k_in), k_out[0], v_in, v_out[0], n, first_bit, end_bit, st);
+  }
+  if (e == hipSuccess) {
+    size_t b = tb;
+    e = rocprim::radix_sort_pairs<SortConfig64>(tmp, b, k_in, k_out[1], v_in, v_out[1], n, first_bit, end_bit, st);
+  }
+  if (e == hipSuccess) {
+    std::vector<unsigned long long> rk[2];
+    std::vector<int> rv[2];
+    for (int v = 0; v < 2 && e == hipSuccess; v++) {
+      rk[v].resize(n); rv[v].resize(n);
+      e = hipMemcpyAsync(rk[v].data(), k_out[v], n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(rv[v].data(), v_out[v], n * sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+      ran = true;
+      same = std::memcmp(rk[0].data(), rk[1].data(), n * sizeof(unsigned long long)) == 0 &&
+             std::memcmp(rv[0].data(), rv[1].data(), n * sizeof(int)) == 0;
+      for (size_t i = 1; same && i < n; i++) same = (rk[0][i - 1] >> first_bit) <= (rk[0][i] >> first_bit);
+    }
+  }
+  (void)hipGetLastError();
+  (void)hipFree(k_in); (void)hipFree(v_in); (void)hipFree(tmp);
+  for (int v = 0; v < 2; v++) { (void)hipFree(k_out[v]); (void)hipFree(v_out[v]); }
+  nbh::onesweep::self_test_report(ran && same, "Barnes-Hut (64-bit keys, index payload)");
+#else
+  (void)st;
+#endif
 }
 
 extern "C" int nbody_hip_tree_destroy(nbody_hip_tree* g) {
@@ -1620,7 +1691,7 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     bool own_sort = false;
     size_t sort_words = 0;
     if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0) {
-      own_sort = NBH_BH_OWN_SORT && n >= g->own_sort_from;
+      own_sort = NBH_BH_OWN_SORT && onesweep::usable() && n >= g->own_sort_from;
       if (own_sort) sort_words = onesweep::clear_words<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(n, (unsigned)first_bit, (unsigned)key_bits);
     }
     int hist_places = 0;

@@ -215,6 +215,32 @@ inline bool runtime_alive() noexcept {
   }                                \
   return NBODY_HIP_OK;
 
+// Entry points that work on SEVERAL devices (the sharded systems, the communicator) hipSetDevice their way through the
+// local ranks; the caller's current device is put back on every exit path -- the facade and the reference model are
+// "current device, null stream" (ref: include/nbody/force_calculator.hpp:8-19), so a caller's next allocation or
+// null-stream launch must land where it was before the call.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() noexcept {
+    try {
+      if (hipGetDevice(&prev) != hipSuccess) {
+        prev = -1;
+        (void)hipGetLastError();
+      }
+    } catch (...) {  // (a runtime that is already gone: see runtime_alive)
+      prev = -1;
+    }
+  }
+  ~DeviceGuard() {
+    try {
+      if (prev >= 0) (void)hipSetDevice(prev);
+    } catch (...) {
+    }
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace nbh

@@ -14,19 +14,65 @@
 //
 // Two more launches go when the caller helps: `cleared` (it zeroed the look-back block itself, e.g. in the kernel that
 // writes the keys) and `hist` (it accumulated the digit histograms there too: DigitHistogram below).
+//
+// DEPENDENCY FENCE (round 4).  onesweep_histograms / onesweep_scan_histograms / onesweep_iteration, onesweep_lookback_state
+// and block_id_wrapper live in rocprim::detail -- a private namespace with no compatibility promise -- and this driver
+// re-states the temporary-storage layout their decoupled look-back expects.  So:
+//   * compile time: the driver exists only for the rocPRIM version it was written and tested against
+//     (NBH_ONESWEEP_TESTED_ROCPRIM = 4.2.0 = ROCm 7.2); with any other version NBH_ONESWEEP_AVAILABLE is 0 and the callers
+//     (barnes_hut.hip, spatial_hash.hip) compile to the public rocprim::radix_sort_pairs alone.  -DNBH_ONESWEEP_FORCE=1
+//     overrides the check for someone porting it to a newer rocPRIM (the run-time test below still applies);
+//   * run time: the first tree / grid created in a process sorts one buffer with both paths and compares every output
+//     word (sort_self_test in the two callers; ~1 ms once); a mismatch switches the process to the public sort and
+//     says so on stderr (nbody_hip_sort_info reports which sort runs);
+//   * tests: tests/test_sort_gpu.py compares the two paths' permutations and runs trees and grids on both.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdio>
 #include <iterator>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/rocprim_version.hpp>
+
+#define NBH_ONESWEEP_TESTED_ROCPRIM 400200
+#ifndef NBH_ONESWEEP_FORCE
+#define NBH_ONESWEEP_FORCE 0
+#endif
+#if NBH_ONESWEEP_FORCE || (defined(ROCPRIM_VERSION) && ROCPRIM_VERSION == NBH_ONESWEEP_TESTED_ROCPRIM)
+#define NBH_ONESWEEP_AVAILABLE 1
+#else
+#define NBH_ONESWEEP_AVAILABLE 0
+#endif
 
 namespace nbh {
 namespace onesweep {
 
+// process-wide verdict of the run-time self-tests: 0 = not run yet, 1 = the driver's output equals the public sort's,
+// 2 = it does not (or the test could not run): the driver is not used
+inline std::atomic<int>& self_test_state() {
+  static std::atomic<int> s{0};
+  return s;
+}
+inline bool usable() { return NBH_ONESWEEP_AVAILABLE && self_test_state().load(std::memory_order_acquire) != 2; }
+inline void self_test_report(bool same, const char* who) {
+  int expect = 0;
+  if (same) {
+    self_test_state().compare_exchange_strong(expect, 1);
+  } else {
+    self_test_state().store(2, std::memory_order_release);
+    std::fprintf(stderr, "libnbody_hip: the Onesweep driver (csrc/onesweep.h, rocPRIM internals of version %d) does not reproduce "
+                         "rocprim::radix_sort_pairs in the %s self-test; the public sort is used instead\n",
+                 (int)ROCPRIM_VERSION, who);
+  }
+}
+
 constexpr unsigned kHistBlock = 256, kHistItems = 12;
 constexpr unsigned kPassBlock = 1024, kPassItems = 8;
+
+#if NBH_ONESWEEP_AVAILABLE
 using BlockId = rocprim::detail::block_id_wrapper<unsigned int, true>;
 using Lookback = rocprim::detail::onesweep_lookback_state;
 
@@ -79,6 +125,8 @@ __global__ __launch_bounds__(kPassBlock) void pass_kernel(KI keys_in, KO keys_ou
       cur_bits, full_blocks, bid);
 }
 
+#endif  // NBH_ONESWEEP_AVAILABLE
+
 // Digit histograms of up to PLACES digit places in LDS, for a kernel that has the keys in registers anyway.
 //   __shared__ unsigned int h[PLACES << RB];  zero(h); __syncthreads(); ... add(h, key >> begin_bit, places) per key ...
 //   __syncthreads(); flush(h, places, ..., global_counts, copy_stride)   -- only the bins that are not empty
@@ -118,6 +166,7 @@ inline size_t clear_words(size_t n, unsigned int begin_bit, unsigned int end_bit
   return places * R + R + places + places * blocks * R;
 }
 
+#if NBH_ONESWEEP_AVAILABLE
 // tmp == nullptr: size query.  keys_in may not alias the temporary arrays; vals_in / vals_out may be any iterators
 // whose value type is VT (the temporary value array holds VT).
 template <unsigned RB, class Key, class VI, class VO>
@@ -194,6 +243,14 @@ hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, const Key* keys_in, Key* key
   }
   return hipGetLastError();
 }
+#else   // another rocPRIM: no driver; the callers never reach these (usable() is false), they only have to compile
+template <unsigned RB, class Key, class VI, class VO>
+hipError_t sort_pairs(void*, size_t& tmp_bytes, const Key*, Key*, VI, VO, size_t, unsigned int, unsigned int, hipStream_t,
+                      bool = false, unsigned int* = nullptr, int = 1, unsigned int = 0) {
+  tmp_bytes = 0;
+  return hipErrorNotSupported;
+}
+#endif  // NBH_ONESWEEP_AVAILABLE
 
 }  // namespace onesweep
 }  // namespace nbh

@@ -144,6 +144,7 @@ extern "C" int nbody_hip_pair_schedule(int world, int rank, size_t S, size_t row
 }
 
 extern "C" int nbody_hip_comm_init_all(int ndev, const int* devices, int transport, nbody_hip_comm** out) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null output pointer");
   *out = nullptr;
   if (ndev < 1 || ndev > NBODY_HIP_MAX_RANKS)
@@ -212,6 +213,7 @@ extern "C" int nbody_hip_comm_unique_id(nbody_hip_comm_id* id) {
 
 extern "C" int nbody_hip_comm_init_rank(int device, int rank, int world, const nbody_hip_comm_id* id,
                                         nbody_hip_comm** out) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!out || !id) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   *out = nullptr;
   if (world < 1 || world > NBODY_HIP_MAX_RANKS || rank < 0 || rank >= world)
@@ -249,6 +251,7 @@ extern "C" int nbody_hip_comm_info(const nbody_hip_comm* c, int* world, int* nlo
 }
 
 extern "C" int nbody_hip_comm_destroy(nbody_hip_comm* c) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!c) return NBODY_HIP_OK;
   NBH_DESTROY_BEGIN
   if (c->transport == NBODY_HIP_TRANSPORT_RCCL) {
@@ -321,6 +324,7 @@ static void shard_release(Shard& s) {
 }
 
 extern "C" int nbody_hip_sharded_direct_destroy(nbody_hip_sharded_direct* s) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBODY_HIP_OK;
   NBH_DESTROY_BEGIN
   for (auto& x : s->sh) shard_release(x);
@@ -330,6 +334,7 @@ extern "C" int nbody_hip_sharded_direct_destroy(nbody_hip_sharded_direct* s) {
 
 extern "C" int nbody_hip_sharded_direct_create(nbody_hip_comm* comm, size_t n, float G, float eps,
                                                nbody_hip_sharded_direct** out) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!comm || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   *out = nullptr;
   if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
@@ -414,6 +419,7 @@ extern "C" int nbody_hip_sharded_direct_create(nbody_hip_comm* comm, size_t n, f
 extern "C" int nbody_hip_sharded_direct_set_state(nbody_hip_sharded_direct* s, const float* x, const float* y,
                                                   const float* z, const float* mass, const float* vx,
                                                   const float* vy, const float* vz) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!x || !y || !z || !mass) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if ((vx || vy || vz) && !(vx && vy && vz)) return NBH_FAIL(NBODY_HIP_ERR_STATE, "velocity arrays: all three or none");
@@ -580,6 +586,7 @@ static int force_phase(nbody_hip_sharded_direct* s, bool gathered, bool kick, fl
 }
 
 extern "C" int nbody_hip_sharded_direct_forces(nbody_hip_sharded_direct* s) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state (call nbody_hip_sharded_direct_set_state first)");
   return force_phase(s, false, false, 0.f, s->cur);
@@ -597,6 +604,7 @@ static int one_step(nbody_hip_sharded_direct* s, float dt) {
 }
 
 extern "C" int nbody_hip_sharded_direct_step(nbody_hip_sharded_direct* s, float dt, int steps) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state (call nbody_hip_sharded_direct_set_state first)");
   if (!(dt > 0.0f) || !(dt <= 1.0f)) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Time step must be in range (0, 1]");
@@ -606,6 +614,7 @@ extern "C" int nbody_hip_sharded_direct_step(nbody_hip_sharded_direct* s, float 
 }
 
 extern "C" int nbody_hip_sharded_direct_synchronize(nbody_hip_sharded_direct* s) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   for (auto& x : s->sh) {
     NBH_HIP(hipSetDevice(x.device));
@@ -617,6 +626,7 @@ extern "C" int nbody_hip_sharded_direct_synchronize(nbody_hip_sharded_direct* s)
 
 extern "C" int nbody_hip_sharded_direct_time_steps(nbody_hip_sharded_direct* s, float dt, int warmup, int steps,
                                                    float* ms_per_step) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s || !ms_per_step) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (steps <= 0 || warmup < 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "bad timing arguments");
   if (int rc = nbody_hip_sharded_direct_step(s, dt, warmup)) return rc;
@@ -671,6 +681,7 @@ static int gather_rows(nbody_hip_sharded_direct* s, int which /*0 vel, 1 acc*/) 
 
 extern "C" int nbody_hip_sharded_direct_get_state(nbody_hip_sharded_direct* s, float* x, float* y, float* z, float* vx,
                                                   float* vy, float* vz, float* ax, float* ay, float* az, int gather) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state");
   if (int rc = nbody_hip_sharded_direct_synchronize(s)) return rc;
@@ -724,6 +735,7 @@ extern "C" int nbody_hip_sharded_direct_get_state(nbody_hip_sharded_direct* s, f
 }
 
 extern "C" int nbody_hip_sharded_direct_energies(nbody_hip_sharded_direct* s, double* kinetic, double* potential) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state");
   if (int rc = nbody_hip_sharded_direct_synchronize(s)) return rc;
@@ -771,6 +783,7 @@ extern "C" int nbody_hip_sharded_direct_energies(nbody_hip_sharded_direct* s, do
 
 // the plugin form: the whole system in d (SoA, on the first local rank's device) -> d->acc_*
 extern "C" int nbody_hip_sharded_direct_compute_forces(nbody_hip_sharded_direct* s, nbody_particle_data* d) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!d) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null particle data");
   if (d->count != s->n) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "particle count %zu does not match the system's %zu", d->count, s->n);

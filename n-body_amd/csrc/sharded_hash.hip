@@ -162,6 +162,7 @@ static void hshard_release(HShard& x) {
 }
 
 extern "C" int nbody_hip_sharded_hash_destroy(nbody_hip_sharded_hash* s) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBODY_HIP_OK;
   NBH_DESTROY_BEGIN
   for (auto& x : s->sh) hshard_release(x);
@@ -171,6 +172,7 @@ extern "C" int nbody_hip_sharded_hash_destroy(nbody_hip_sharded_hash* s) {
 
 extern "C" int nbody_hip_sharded_hash_create(nbody_hip_comm* comm, size_t n, float G, float eps, float cell_size,
                                              float cutoff, nbody_hip_sharded_hash** out) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!comm || !out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   *out = nullptr;
   if (n == 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Particle count must be greater than 0");
@@ -313,6 +315,7 @@ static int grid_for(HShard& x, nbody_hip_grid** g, size_t* cap, size_t need, flo
 // initial ownership: every process evaluates the same global grid on the host
 extern "C" int nbody_hip_sharded_hash_set_state(nbody_hip_sharded_hash* s, const float* x, const float* y, const float* z,
                                                 const float* mass, const float* vx, const float* vy, const float* vz) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!x || !y || !z || !mass) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if ((vx || vy || vz) && !(vx && vy && vz)) return NBH_FAIL(NBODY_HIP_ERR_STATE, "velocity arrays: all three or none");
@@ -724,6 +727,7 @@ static void adopt_new_accelerations(nbody_hip_sharded_hash* s) {
 }
 
 extern "C" int nbody_hip_sharded_hash_forces(nbody_hip_sharded_hash* s) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state (call nbody_hip_sharded_hash_set_state first)");
   if (int rc = hash_force_phase(s)) return rc;
@@ -732,6 +736,7 @@ extern "C" int nbody_hip_sharded_hash_forces(nbody_hip_sharded_hash* s) {
 }
 
 extern "C" int nbody_hip_sharded_hash_step(nbody_hip_sharded_hash* s, float dt, int steps) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state (call nbody_hip_sharded_hash_set_state first)");
   if (!(dt > 0.0f) || !(dt <= 1.0f)) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Time step must be in range (0, 1]");
@@ -749,6 +754,7 @@ extern "C" int nbody_hip_sharded_hash_step(nbody_hip_sharded_hash* s, float dt, 
 }
 
 extern "C" int nbody_hip_sharded_hash_synchronize(nbody_hip_sharded_hash* s) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   for (auto& x : s->sh) {
     NBH_HIP(hipSetDevice(x.device));
@@ -774,6 +780,7 @@ extern "C" int nbody_hip_sharded_hash_info(const nbody_hip_sharded_hash* s, int 
 // host arrays of n_total floats indexed by the bodies' GLOBAL ids; every process fills the rows of its local ranks
 extern "C" int nbody_hip_sharded_hash_get_state(nbody_hip_sharded_hash* s, float* x, float* y, float* z, float* vx, float* vy,
                                                 float* vz, float* ax, float* ay, float* az) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null system");
   if (!s->have_state) return NBH_FAIL(NBODY_HIP_ERR_STATE, "no body state");
   if (int rc = nbody_hip_sharded_hash_synchronize(s)) return rc;
@@ -803,6 +810,7 @@ extern "C" int nbody_hip_sharded_hash_get_state(nbody_hip_sharded_hash* s, float
 }
 
 extern "C" int nbody_hip_sharded_hash_time_steps(nbody_hip_sharded_hash* s, float dt, int warmup, int steps, float* ms_per_step) {
+  nbh::DeviceGuard dev_guard;  // the caller's current device is restored on return
   if (!s || !ms_per_step) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
   if (steps <= 0 || warmup < 0) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "bad timing arguments");
   if (int rc = nbody_hip_sharded_hash_step(s, dt, warmup)) return rc;

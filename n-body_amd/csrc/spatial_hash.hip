@@ -31,6 +31,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -1386,7 +1387,7 @@ static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned i
                                       unsigned int* hist = nullptr) {
   auto vin = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_in, rocprim::make_counting_iterator<int>(0)));
   auto vout = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_out, idx_out));
-#if NBH_HASH_OWN_SORT
+#if NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE
   // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (one fill instead of five, onesweep.h)
   if (!temp) {  // size query: room for either path
     size_t a = 0, b = 0;
@@ -1402,6 +1403,78 @@ static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned i
                                                           vin, vout, n, 0u, (unsigned)bits, st, cleared, hist, nbh::kHistCopies, nbh::kHistWords);
 #endif
   return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vin, vout, n, 0, bits, st);
+}
+
+// Run-time half of the dependency fence of onesweep.h: ONE buffer (200,000 bodies on a 20-bit grid, every key value
+// shared by several bodies so that stability shows) through the Onesweep driver and through the public
+// rocprim::radix_sort_pairs; keys, bodies and indices must agree word for word.  Once per process (the first grid).
+static void grid_sort_self_test(hipStream_t st) {
+#if NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE
+  if (nbh::onesweep::self_test_state().load(std::memory_order_acquire) != 0) return;
+  const size_t n = 200000;
+  const int bits = 20;
+  std::vector<unsigned int> hk(n);
+  std::vector<float4> hb(n);
+  unsigned int x = 12345u;
+  for (size_t i = 0; i < n; i++) {
+    x = x * 1664525u + 1013904223u;
+    hk[i] = (x >> 9) & ((1u << bits) - 1u) & ~0x3fu;  // 2^14 distinct cells: ~12 bodies each
+    hb[i] = make_float4((float)i, (float)hk[i], 0.f, 1.f);
+  }
+  unsigned int *k_in = nullptr, *k_out[2] = {nullptr, nullptr};
+  float4 *b_in = nullptr, *b_out[2] = {nullptr, nullptr};
+  int* i_out[2] = {nullptr, nullptr};
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  bool ran = false, same = false;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&k_in), n * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b_in), n * sizeof(float4));
+  for (int v = 0; v < 2 && e == hipSuccess; v++) {
+    e = hipMalloc(reinterpret_cast<void**>(&k_out[v]), n * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b_out[v]), n * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&i_out[v]), n * sizeof(int));
+  }
+  if (e == hipSuccess) e = sort_bodies_by_cell(nullptr, tmp_bytes, k_in, k_out[0], b_in, b_out[0], i_out[0], n, bits, st);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16);
+  if (e == hipSuccess) e = hipMemcpyAsync(k_in, hk.data(), n * sizeof(unsigned int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(b_in, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice, st);
+  for (int v = 0; v < 2 && e == hipSuccess; v++) {  // v = 0: the driver (own_from = 0), v = 1: the public sort
+    size_t tb = tmp_bytes;
+    e = sort_bodies_by_cell(tmp, tb, k_in, k_out[v], b_in, b_out[v], i_out[v], n, bits, st, v == 0 ? (size_t)0 : ~(size_t)0);
+  }
+  if (e == hipSuccess) {
+    std::vector<unsigned int> rk[2];
+    std::vector<float4> rb[2];
+    std::vector<int> ri[2];
+    for (int v = 0; v < 2 && e == hipSuccess; v++) {
+      rk[v].resize(n); rb[v].resize(n); ri[v].resize(n);
+      e = hipMemcpyAsync(rk[v].data(), k_out[v], n * sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(rb[v].data(), b_out[v], n * sizeof(float4), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(ri[v].data(), i_out[v], n * sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+      ran = true;
+      same = std::memcmp(rk[0].data(), rk[1].data(), n * sizeof(unsigned int)) == 0 &&
+             std::memcmp(rb[0].data(), rb[1].data(), n * sizeof(float4)) == 0 &&
+             std::memcmp(ri[0].data(), ri[1].data(), n * sizeof(int)) == 0;
+      for (size_t i = 1; same && i < n; i++) same = rk[0][i - 1] <= rk[0][i];
+    }
+  }
+  (void)hipGetLastError();
+  (void)hipFree(k_in); (void)hipFree(b_in); (void)hipFree(tmp);
+  for (int v = 0; v < 2; v++) { (void)hipFree(k_out[v]); (void)hipFree(b_out[v]); (void)hipFree(i_out[v]); }
+  nbh::onesweep::self_test_report(ran && same, "spatial-hash (32-bit keys, body + index payload)");
+#else
+  (void)st;
+#endif
+}
+
+extern "C" int nbody_hip_sort_info(int* driver_compiled, int* self_test, int* rocprim_version) {
+  if (driver_compiled) *driver_compiled = NBH_ONESWEEP_AVAILABLE;
+  if (self_test) *self_test = nbh::onesweep::self_test_state().load(std::memory_order_acquire);
+  if (rocprim_version) *rocprim_version = (int)ROCPRIM_VERSION;
+  return NBODY_HIP_OK;
 }
 
 struct nbody_hip_grid {
@@ -1474,6 +1547,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   g->ctx = ctx;
   g->max_particles = max_particles;
   g->own_sort_from = nbh::own_sort_from(nbh::kOwnSortFromGrid);
+  grid_sort_self_test(ctx->stream);  // (once per process: the Onesweep driver against the public sort, onesweep.h)
   g->cell_size = cell_size;
   const size_t n = max_particles;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_enc), 8 * sizeof(unsigned int));
@@ -1613,7 +1687,7 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   }
   const int sort_bits = bits_for(g->info.total);
-  const bool own_sort = NBH_HASH_OWN_SORT && n >= g->own_sort_from;
+  const bool own_sort = NBH_HASH_OWN_SORT && nbh::onesweep::usable() && n >= g->own_sort_from;
   const size_t zero_words = own_sort ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)sort_bits) : 0;
   const int hist_places = own_sort && sort_bits <= kHistPlaces * NBH_HASH_RADIX_BITS
                               ? (sort_bits + NBH_HASH_RADIX_BITS - 1) / NBH_HASH_RADIX_BITS : 0;
