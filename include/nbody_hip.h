@@ -287,6 +287,18 @@ NBODY_HIP_API int nbody_hip_grid_set_slab(nbody_hip_grid* grid, int z_first, int
 NBODY_HIP_API int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* targets, nbody_hip_grid* sources, int z_first,
                                                     int z_count, float cutoff, float G, float eps,
                                                     nbody_float4* acc_out, int accumulate);
+
+/* The boundary pass of a z-slab decomposition without a second grid (round 4).  A rank's own grid (packed build with
+ * nbody_hip_grid_set_slab) can hand one of its z layers to a neighbour READY FOR USE: nbody_hip_grid_export_layer writes
+ * the layer's bodies in cell order (as many as the layer holds) and its start array rebased to 0 (dims[0] * dims[1] + 1
+ * ints).  nbody_hip_grid_forces_layer_packed evaluates the targets of layer z of `grid` against such a layer (which is
+ * layer src_z of the same global grid: same origin, dimensions, cell size), adding to acc_out when accumulate != 0.
+ * Same pair set and arithmetic as the 27-cell search of ref: src/cuda/force_spatial_hash.cu:104-146 restricted to the
+ * source layer's cells. */
+NBODY_HIP_API int nbody_hip_grid_export_layer(nbody_hip_grid* grid, int z, nbody_float4* bodies_out, int* lb_out);
+NBODY_HIP_API int nbody_hip_grid_forces_layer_packed(nbody_hip_grid* grid, int z, const nbody_float4* src_bodies,
+                                                     const int* src_lb, int src_z, float cutoff, float G, float eps,
+                                                     nbody_float4* acc_out, int accumulate);
 /* One partition pass of a rank's bodies after the drift (csrc/slab.hip).  gbox_dev: DEVICE array
  * {min x,y,z, max x,y,z} of ALL ranks' bodies (the all-reduced nbody_hip_bbox_packed result, unpadded);
  * the global grid is derived from it on the device exactly as SpatialHashGrid::build does (ref:

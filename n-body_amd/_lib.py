@@ -123,6 +123,8 @@ PROTOTYPES = {
     "nbody_hip_grid_set_slab": (C.c_int, [_P, C.c_int, C.c_int]),
     "nbody_hip_grid_forces_pair_packed": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P,
                                                     C.c_int]),
+    "nbody_hip_grid_export_layer": (C.c_int, [_P, C.c_int, _P, _P]),
+    "nbody_hip_grid_forces_layer_packed": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float, _P, C.c_int]),
     "nbody_hip_slab_partition": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_int, C.c_int, C.c_int,
                                            _P, _P, _P, _P, _P]),
     "nbody_hip_slab_partition_cuts": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, C.c_float, C.c_int, C.c_int, C.c_int,

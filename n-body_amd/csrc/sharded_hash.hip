@@ -103,8 +103,12 @@ struct HShard {
   size_t got_cap = 0;
   float4 *halo_out = nullptr, *halo_in = nullptr, *cat = nullptr, *cat_acc = nullptr;
   size_t halo_out_cap = 0, halo_in_cap = 0, cat_cap = 0;
-  nbody_hip_grid *g_own = nullptr, *g_halo = nullptr, *g_one = nullptr;
-  size_t g_own_cap = 0, g_halo_cap = 0, g_one_cap = 0;
+  // the start arrays of the exchanged boundary layers (nbody_hip_grid_export_layer): [2][lb_cap] ints each; out: my
+  // lowest / highest layer, in: the layer below my slab / above it
+  int *halo_lb_out = nullptr, *halo_lb_in = nullptr;
+  size_t lb_cap = 0;
+  nbody_hip_grid *g_own = nullptr, *g_one = nullptr;
+  size_t g_own_cap = 0, g_one_cap = 0;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, t0 = nullptr, t1 = nullptr;
   // per evaluation (host)
   size_t n_leave = 0, n_arrive = 0, n_head = 0, n_tail = 0, n_halo = 0;
@@ -148,10 +152,10 @@ static void hshard_release(HShard& x) {
   (void)hipSetDevice(x.device);
   if (x.compute) (void)hipStreamSynchronize(x.compute);
   if (x.comm) (void)hipStreamSynchronize(x.comm);
-  for (nbody_hip_grid* g : {x.g_own, x.g_halo, x.g_one})
+  for (nbody_hip_grid* g : {x.g_own, x.g_one})
     if (g) (void)nbody_hip_grid_destroy(g);
   void* dev[] = {x.posm, x.vel, x.acc, x.acc2, x.gid, x.rows, x.holes, x.stats, x.sum_block, x.box, x.enc,
-                 x.got, x.halo_out, x.halo_in, x.cat, x.cat_acc};
+                 x.got, x.halo_out, x.halo_in, x.cat, x.cat_acc, x.halo_lb_out, x.halo_lb_in};
   for (void* p : dev) (void)hipFree(p);
   if (x.h_block) (void)hipHostFree(x.h_block);
   for (hipEvent_t e : {x.ev_a, x.ev_b, x.ev_c, x.ev_d, x.t0, x.t1})
@@ -570,8 +574,18 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
     }
   }
   // -- 6, 7: own grids; the boundary layers leave for the neighbours ---------------------------------------------------
-  bool two_grid_all = true;
-  struct Plan { int z_lo, z_hi, lower, upper, z0h, z1h; bool two_grid; };
+  // Dense slabs (every rank's grid carries per-cell start arrays) take the two-grid form: own x own while the boundary
+  // layers travel, then each boundary layer against the neighbour's layer AS THE NEIGHBOUR'S GRID HOLDS IT -- bodies in
+  // cell order plus the layer's start array (nbody_hip_grid_export_layer): the receiver bins nothing.  The decision is
+  // taken from the send matrix and the slab map, which every process holds alike: all ranks take the same form.
+  const size_t lb_len = (size_t)layer_cells + 1;
+  bool all_dense = true;
+  for (int r = 0; r < W; r++) {
+    long long n_r = 0;
+    for (int q = 0; q < W; q++) n_r += M[q * W + r];
+    if (n_r > 0 && (long long)(map.hi[r] - map.lo[r]) * layer_cells > 4LL * n_r + 4096) all_dense = false;
+  }
+  struct Plan { int z_lo, z_hi, lower, upper; size_t in_lower; };
   std::vector<Plan> plan(s->sh.size());
   for (size_t k = 0; k < s->sh.size(); k++) {
     HShard& x = s->sh[k];
@@ -594,15 +608,9 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
         in_upper = (size_t)hist[pl.z_hi];
       }
     }
+    pl.in_lower = in_lower;
     x.n_halo = in_lower + in_upper;
     s->halo_bodies += x.n_halo;
-    pl.z0h = pl.z_lo - 1 < 0 ? 0 : pl.z_lo - 1;
-    pl.z1h = pl.z_hi + 1 > gz ? gz : pl.z_hi + 1;
-    // both grids dense enough for the per-cell start arrays of the two-grid kernel?  (stricter than the library's own
-    // test, which builds them up to 16 cells per body: safe)
-    pl.two_grid = (long long)(pl.z_hi - pl.z_lo) * layer_cells <= 4LL * (long long)x.n + 4096 &&
-                  (x.n_halo == 0 || (long long)(pl.z1h - pl.z0h) * layer_cells <= 4LL * (long long)x.n_halo + 4096);
-    two_grid_all = two_grid_all && (pl.two_grid || x.n == 0);
     NBH_HIP(hipSetDevice(x.device));
     if (x.n) {
       if (int rc = grid_for(x, &x.g_own, &x.g_own_cap, x.n, s->cell)) return rc;
@@ -624,39 +632,68 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
       x.halo_in_cap = x.n_halo + x.n_halo / 4 + 1024;
       NBH_HIP(hipMalloc(reinterpret_cast<void**>(&x.halo_in), x.halo_in_cap * sizeof(float4)));
     }
+    if (all_dense && W > 1 && lb_len > x.lb_cap) {
+      NBH_HIP(hipStreamSynchronize(x.comm));
+      NBH_HIP(hipStreamSynchronize(x.compute));
+      (void)hipFree(x.halo_lb_out); (void)hipFree(x.halo_lb_in);
+      x.halo_lb_out = x.halo_lb_in = nullptr;
+      x.lb_cap = lb_len + lb_len / 4 + 64;
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&x.halo_lb_out), 2 * x.lb_cap * sizeof(int)));
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&x.halo_lb_in), 2 * x.lb_cap * sizeof(int)));
+    }
     // its lowest layer is the head of the cell order, its highest the tail
-    if (x.n_head)
-      if (int rc = nbody_hip_grid_sorted_bodies(x.g_own, 0, x.n_head, reinterpret_cast<nbody_float4*>(x.halo_out))) return rc;
-    if (x.n_tail)
-      if (int rc = nbody_hip_grid_sorted_bodies(x.g_own, x.n - x.n_tail, x.n_tail, reinterpret_cast<nbody_float4*>(x.halo_out + x.n_head)))
-        return rc;
+    if (all_dense) {
+      if (x.n_head)
+        if (int rc = nbody_hip_grid_export_layer(x.g_own, pl.z_lo, reinterpret_cast<nbody_float4*>(x.halo_out), x.halo_lb_out)) return rc;
+      if (x.n_tail)
+        if (int rc = nbody_hip_grid_export_layer(x.g_own, pl.z_hi - 1, reinterpret_cast<nbody_float4*>(x.halo_out + x.n_head),
+                                                 x.halo_lb_out + x.lb_cap))
+          return rc;
+    } else {
+      if (x.n_head)
+        if (int rc = nbody_hip_grid_sorted_bodies(x.g_own, 0, x.n_head, reinterpret_cast<nbody_float4*>(x.halo_out))) return rc;
+      if (x.n_tail)
+        if (int rc = nbody_hip_grid_sorted_bodies(x.g_own, x.n - x.n_tail, x.n_tail, reinterpret_cast<nbody_float4*>(x.halo_out + x.n_head)))
+          return rc;
+    }
     NBH_HIP(hipEventRecord(x.ev_d, x.compute));
     NBH_HIP(hipStreamWaitEvent(x.comm, x.ev_d, 0));
   }
-  s->two_grid = two_grid_all ? 1 : 0;
+  s->two_grid = all_dense ? 1 : 0;
   if (W > 1) {
     if (rccl) NBH_NCCL(api, api->GroupStart());
     for (size_t k = 0; k < s->sh.size(); k++) {
       HShard& x = s->sh[k];
       const Plan& pl = plan[k];
       NBH_HIP(hipSetDevice(x.device));
-      // receive layout: the lower neighbour's layer first, then the upper neighbour's (source-rank order)
-      const size_t in_lower = pl.lower >= 0 ? (size_t)hist[pl.z_lo - 1] : 0;
+      // receive layout: the lower neighbour's layer first, then the upper neighbour's (source-rank order); start arrays:
+      // slot 0 = the layer below my slab, slot 1 = the layer above it
+      const size_t in_lower = pl.in_lower;
       if (rccl) {
         if (x.n_head) NBH_NCCL(api, api->Send(x.halo_out, x.n_head * 4, ncclFloat, pl.lower, x.nccl, x.comm));
         if (x.n_tail) NBH_NCCL(api, api->Send(x.halo_out + x.n_head, x.n_tail * 4, ncclFloat, pl.upper, x.nccl, x.comm));
         if (in_lower) NBH_NCCL(api, api->Recv(x.halo_in, in_lower * 4, ncclFloat, pl.lower, x.nccl, x.comm));
         if (x.n_halo - in_lower) NBH_NCCL(api, api->Recv(x.halo_in + in_lower, (x.n_halo - in_lower) * 4, ncclFloat, pl.upper, x.nccl, x.comm));
+        if (all_dense) {
+          if (x.n_head) NBH_NCCL(api, api->Send(x.halo_lb_out, lb_len, ncclInt32, pl.lower, x.nccl, x.comm));
+          if (x.n_tail) NBH_NCCL(api, api->Send(x.halo_lb_out + x.lb_cap, lb_len, ncclInt32, pl.upper, x.nccl, x.comm));
+          if (in_lower) NBH_NCCL(api, api->Recv(x.halo_lb_in, lb_len, ncclInt32, pl.lower, x.nccl, x.comm));
+          if (x.n_halo - in_lower) NBH_NCCL(api, api->Recv(x.halo_lb_in + x.lb_cap, lb_len, ncclInt32, pl.upper, x.nccl, x.comm));
+        }
       } else {
         if (x.n_head) {  // my lowest layer is the UPPER halo of the owner of the layer below: behind its lower halo
           HShard* d = s->by_rank[pl.lower];
           const int dz_lo = map.lo[d->rank];
           const size_t d_in_lower = dz_lo > 0 ? (size_t)hist[dz_lo - 1] : 0;
           NBH_HIP(hipMemcpyAsync(d->halo_in + d_in_lower, x.halo_out, x.n_head * sizeof(float4), hipMemcpyDeviceToDevice, x.comm));
+          if (all_dense)
+            NBH_HIP(hipMemcpyAsync(d->halo_lb_in + d->lb_cap, x.halo_lb_out, lb_len * sizeof(int), hipMemcpyDeviceToDevice, x.comm));
         }
         if (x.n_tail) {  // my highest layer is the LOWER halo of the owner of the layer above: at the front
           HShard* d = s->by_rank[pl.upper];
           NBH_HIP(hipMemcpyAsync(d->halo_in, x.halo_out + x.n_head, x.n_tail * sizeof(float4), hipMemcpyDeviceToDevice, x.comm));
+          if (all_dense)
+            NBH_HIP(hipMemcpyAsync(d->halo_lb_in, x.halo_lb_out + x.lb_cap, lb_len * sizeof(int), hipMemcpyDeviceToDevice, x.comm));
         }
       }
     }
@@ -670,12 +707,12 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
   for (size_t k = 0; k < s->sh.size(); k++) {
     HShard& x = s->sh[k];
     const Plan& pl = plan[k];
-    if (x.n && pl.two_grid)
+    if (x.n && all_dense)
       if (int rc = nbody_hip_grid_forces_pair_packed(x.g_own, x.g_own, pl.z_lo, pl.z_hi - pl.z_lo, s->cutoff, s->G, s->eps,
                                                      reinterpret_cast<nbody_float4*>(x.acc2), 0))
         return rc;
   }
-  // -- 9: the boundary layers against the received halo ------------------------------------------------------------------
+  // -- 9: the boundary layers against the received layers ----------------------------------------------------------------
   for (size_t k = 0; k < s->sh.size(); k++) {
     HShard& x = s->sh[k];
     const Plan& pl = plan[k];
@@ -689,17 +726,18 @@ static int hash_force_phase(nbody_hip_sharded_hash* s, const float* drift_dt = n
         if (pl.upper >= 0) NBH_HIP(hipStreamWaitEvent(x.compute, s->by_rank[pl.upper]->ev_c, 0));
       }
     }
-    if (pl.two_grid) {
-      if (x.n_halo) {
-        if (int rc = grid_for(x, &x.g_halo, &x.g_halo_cap, x.n_halo, s->cell)) return rc;
-        if (int rc = nbody_hip_grid_set_slab(x.g_halo, pl.z0h, pl.z1h - pl.z0h)) return rc;
-        if (int rc = nbody_hip_grid_build_packed(x.g_halo, reinterpret_cast<nbody_float4*>(x.halo_in), x.n_halo, bounds)) return rc;
-        const int zs[2] = {pl.z_lo, pl.z_hi - 1};
-        for (int q = 0; q < (zs[0] == zs[1] ? 1 : 2); q++)
-          if (int rc = nbody_hip_grid_forces_pair_packed(x.g_own, x.g_halo, zs[q], 1, s->cutoff, s->G, s->eps,
-                                                         reinterpret_cast<nbody_float4*>(x.acc2), 1))
-            return rc;
-      }
+    if (all_dense) {
+      // my lowest layer against the layer below the slab, my highest against the layer above it (the same layer twice when
+      // the slab is one layer thick); an empty received layer has nothing to add
+      if (pl.in_lower)
+        if (int rc = nbody_hip_grid_forces_layer_packed(x.g_own, pl.z_lo, reinterpret_cast<nbody_float4*>(x.halo_in), x.halo_lb_in,
+                                                        pl.z_lo - 1, s->cutoff, s->G, s->eps, reinterpret_cast<nbody_float4*>(x.acc2), 1))
+          return rc;
+      if (x.n_halo - pl.in_lower)
+        if (int rc = nbody_hip_grid_forces_layer_packed(x.g_own, pl.z_hi - 1, reinterpret_cast<nbody_float4*>(x.halo_in + pl.in_lower),
+                                                        x.halo_lb_in + x.lb_cap, pl.z_hi, s->cutoff, s->G, s->eps,
+                                                        reinterpret_cast<nbody_float4*>(x.acc2), 1))
+          return rc;
     } else {  // too sparse for the per-cell start arrays: one grid over own + halo bodies
       const size_t nall = x.n + x.n_halo;
       if (nall > x.cat_cap) {

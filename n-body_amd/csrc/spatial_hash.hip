@@ -1357,6 +1357,18 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force2_kernel(
 #undef NBH_PREFETCH
 }
 
+// One z layer of a slab grid as a neighbour rank needs it for its boundary pass (sharded path): the layer's bodies in cell
+// order and the layer's start array rebased to 0 -- a ready-made CellGridView of that layer, so the receiver bins nothing
+// (round 3 built a second grid from the received bodies: six launches and a merge sort per rank and step).
+__global__ __launch_bounds__(kBlock) void layer_export_kernel(const float4* __restrict__ sorted, const int* __restrict__ lb_layer,
+                                                              int layer_cells, float4* __restrict__ bodies_out,
+                                                              int* __restrict__ lb_out) {
+  const int first = lb_layer[0], count = lb_layer[layer_cells] - first;
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) bodies_out[i] = sorted[first + i];
+  for (int c = blockIdx.x * kBlock + threadIdx.x; c <= layer_cells; c += stride) lb_out[c] = lb_layer[c] - first;
+}
+
 // z cell coordinate of every body on a given grid (slab assignment of the sharded path)
 __global__ __launch_bounds__(kBlock) void cell_z_kernel(const float4* __restrict__ posm, int n,
                                                         float lo_z, float cell, int gz,
@@ -1509,6 +1521,8 @@ struct nbody_hip_grid {
   unsigned unit_flip = 0;
   unsigned stat_tick = 0;
   int stat_seq = 0;
+  double filter_from_inside = kFilterFromInside;  // bodies per cell from which the filtered form runs when cutoff <= cell
+                                       // (NBH_HASH_FILTER_FROM in the environment at creation: A/B runs)
   int use_units = 1;                   // NBH_HASH_UNITS in the environment at creation: 0 = never (the cell-range form,
                                        // A/B), 2 = always (tests), default 1 = by the statistics of the previous call
   long long lb_capacity = 0;
@@ -1580,6 +1594,10 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
         }
         const char* env = std::getenv("NBH_HASH_UNITS");
         g->use_units = env && env[0] == '0' ? 0 : (env && env[0] == '2' ? 2 : 1);
+        if (const char* ff = std::getenv("NBH_HASH_FILTER_FROM")) {
+          const double v = std::atof(ff);
+          if (v > 0.0) g->filter_from_inside = v;
+        }
       }
     }
   }
@@ -2057,7 +2075,7 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
     if (!g->lb_valid) {
       kern = 1;
     } else if (rho >= (strict ? 0.5 : 1.0)) {
-      kern = rho < 8.0 ? 2 : (rho < (strict ? kFilterFrom : kFilterFromInside) ? 3 : 6);
+      kern = rho < 8.0 ? 2 : (rho < (strict ? kFilterFrom : g->filter_from_inside) ? 3 : 6);
     } else if (g->use_units && g->h_unit_hint_dev && g->lb_count < 0x7fffffffLL) {
       const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
       if (int rc = make_unit_list(ctx, g, view, g->lb_base, g->lb_base + g->lb_count, 64, &prebuilt)) return rc;
@@ -2157,11 +2175,59 @@ extern "C" int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* gt, nbody_hip_g
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
   const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
   int kern = gt->tune_kernel;
-  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < (cutoff > gt->cell_size ? kFilterFrom : kFilterFromInside) ? 3 : 6);
+  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < (cutoff > gt->cell_size ? kFilterFrom : gt->filter_from_inside) ? 3 : 6);
   const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
   const CellGridView sv{gs->d_sorted, gs->d_cell_lb, gs->d_idx_b, gs->lb_base, gs->lb_count};
   return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f || !cut_const_ok(cutoff2), cutoff2, eps2, G, nullptr, nullptr,
                             nullptr, reinterpret_cast<float4*>(acc_out), accumulate ? 1 : 0, gt, accumulate ? 1 : 0);
+}
+
+extern "C" int nbody_hip_grid_export_layer(nbody_hip_grid* g, int z, nbody_float4* bodies_out, int* lb_out) {
+  if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!bodies_out || !lb_out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (g->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid has not been built");
+  if (!g->lb_valid) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid too sparse for per-cell start arrays: no layer to export");
+  const long long layer = (long long)g->info.dims[0] * g->info.dims[1];
+  const long long k0 = (long long)z * layer - g->lb_base;
+  if (z < 0 || z >= g->info.dims[2] || k0 < 0 || k0 + layer > g->lb_count)
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "layer %d is outside the z layers this grid holds", z);
+  nbody_hip_ctx* ctx = g->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  const long long work = layer + 1 > (long long)g->built_count ? layer + 1 : (long long)g->built_count;
+  long long blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(layer_export_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, g->d_sorted, g->d_cell_lb + k0,
+                     (int)layer, reinterpret_cast<float4*>(bodies_out), lb_out);
+  NBH_LAUNCH_CHECK();
+  return NBODY_HIP_OK;
+}
+
+extern "C" int nbody_hip_grid_forces_layer_packed(nbody_hip_grid* gt, int z, const nbody_float4* src_bodies, const int* src_lb,
+                                                  int src_z, float cutoff, float G, float eps, nbody_float4* acc_out,
+                                                  int accumulate) {
+  if (!gt) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
+  if (!src_bodies || !src_lb || !acc_out) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null argument");
+  if (gt->built_count == 0) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid has not been built");
+  if (!(cutoff > 0.0f) || !(cutoff < INFINITY))
+    return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "Spatial hash cutoff must be positive and finite");
+  if (!gt->lb_valid) return NBH_FAIL(NBODY_HIP_ERR_STATE, "grid too sparse for the two-grid force kernel (no per-cell start array)");
+  const int gx = gt->info.dims[0], gy = gt->info.dims[1], gz = gt->info.dims[2];
+  if (z < 0 || z >= gz || src_z < 0 || src_z >= gz) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "layer outside the grid");
+  nbody_hip_ctx* ctx = gt->ctx;
+  NBH_HIP(hipSetDevice(ctx->device));
+  const long long layer = (long long)gx * gy;
+  long long c0 = (long long)z * layer, c1 = c0 + layer;
+  if (c0 < gt->lb_base) c0 = gt->lb_base;
+  if (c1 > gt->lb_base + gt->lb_count) c1 = gt->lb_base + gt->lb_count;
+  const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
+  const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
+  int kern = gt->tune_kernel;
+  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < (cutoff > gt->cell_size ? kFilterFrom : gt->filter_from_inside) ? 3 : 6);
+  const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
+  // the source layer as the sender exported it (nbody_hip_grid_export_layer): cells outside it hold nothing
+  const CellGridView sv{reinterpret_cast<const float4*>(src_bodies), src_lb, nullptr, (long long)src_z * layer, layer};
+  return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f || !cut_const_ok(cutoff2), cutoff2, eps2, G, nullptr,
+                            nullptr, nullptr, reinterpret_cast<float4*>(acc_out), accumulate ? 1 : 0, gt, 1);
 }
 
 extern "C" int nbody_hip_bbox_packed(nbody_hip_ctx* ctx, const nbody_float4* posm, size_t n,
