@@ -72,6 +72,11 @@ def parse():
     ap.add_argument("--sharded-host", choices=["cabi", "torch"], default="cabi",
                     help="Direct on N ranks: cabi = the whole step behind the C ABI (include/nbody_hip_comm.h: RCCL "
                          "from C++, one call per step); torch = the torch.distributed host (n-body_amd/distributed.py)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="Direct, one GPU: before the timed run, collect FETCH_SIZE and WRITE_SIZE of the dominant kernel with "
+                         "two rocprofv3 --pmc passes over this same command (child processes started BEFORE this process "
+                         "touches the GPU; counters never combined with other trace domains) and report the HBM bytes per "
+                         "launch they give as roofline.traffic instead of the committed profiles/pmc_summary.json value")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--kernel-iters", type=int, default=3, help="launches for the roofline timing")
     return ap.parse_args()
@@ -168,6 +173,59 @@ def read_pmc_issue(name):
         return out
     except Exception:
         return None
+
+
+_PMC_MEASURED = None  # {"hbm_bytes_per_launch", ...} of collect_pmc_traffic (--pmc), else None
+
+
+def collect_pmc_traffic(a):
+    """--pmc: HBM bytes per launch of the dominant Direct kernel, measured by two rocprofv3 counter passes over THIS
+    command (FETCH_SIZE and WRITE_SIZE cannot share a pass: MICROARCH.md, rocprofv3 PMC slots), gfx950 corrections as
+    that guide prescribes (both counters in KB; FETCH_SIZE x 2 for wide coalesced reads).  Runs child processes, so it
+    is called before anything initialises the GPU here; the children get --no-clock / --no-cpu-baseline / --no-extra
+    (nothing but the kernels under the counters) and the program under rocprofv3 is python3 itself."""
+    global _PMC_MEASURED
+    import csv
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        return
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over `bench.py --steps 2 --warmup 1 "
+                     f"--bodies {a.n}` in this run: FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes, per launch of the longest "
+                     "Direct kernel"}
+    tmp = tempfile.mkdtemp(prefix="nbody_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    kb = {}
+    for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        d = os.path.join(tmp, name)
+        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--bodies", str(a.n),
+               "--eps", str(a.eps), "--no-cpu-baseline", "--no-extra", "--no-clock", "--kernel-iters", "1"]
+        if a.atomics:
+            cmd.append("--atomics")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            per_kernel = {}
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for row in csv.DictReader(open(os.path.join(root, f))):
+                            if row["Counter_Name"] != ctr or "direct" not in row["Kernel_Name"]:
+                                continue
+                            k = per_kernel.setdefault(row["Kernel_Name"].split("(")[0], {"v": {}, "ns": 0})
+                            k["v"][row["Dispatch_Id"]] = k["v"].get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                            k["ns"] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            if not per_kernel:
+                return
+            kname, best = max(per_kernel.items(), key=lambda kv: kv[1]["ns"])  # the dominant kernel
+            kb[name] = sum(best["v"].values()) / len(best["v"])
+            out["kernel"] = kname.replace("void ", "")
+        except Exception:
+            return
+        finally:
+            shutil.rmtree(os.path.join(tmp, name), ignore_errors=True)
+    out["FETCH_SIZE_KB"], out["WRITE_SIZE_KB"] = kb["fetch"], kb["write"]
+    out["hbm_bytes_per_launch"] = 2.0 * 1024.0 * kb["fetch"] + 1024.0 * kb["write"]
+    _PMC_MEASURED = out
 
 
 def read_pmc_traffic():
@@ -449,7 +507,7 @@ def other_roofline(a, nb, ps, torch, workload):
         return {"kernel": kernel, "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0,
                 "unit": "GB/s", "frac": nbytes / t / 8e12, "traffic": None, "avg_kernel_ms": t * 1e3,
                 "node_visits_per_s": visits / t, "nodes": st["node_count"],
-                "issue": read_pmc_issue("r03_pmc_bh_pair_kernel.json"),
+                "issue": read_pmc_issue("r04_pmc_bh_pair_kernel.json") or read_pmc_issue("r03_pmc_bh_pair_kernel.json"),
                 "note": "32 B per node record a wave fetches (scalar cache / L2, mostly not HBM) + 16 B per body; "
                         "the walk is latency- and issue-bound, see DESIGN.md 4.5"}
     cs, ce, _, _ = grid.copyCellDataToHost()
@@ -463,11 +521,12 @@ def other_roofline(a, nb, ps, torch, workload):
                 nb27 += pad[dz:dz + gz, dy:dy + gy, dx:dx + gx]
     pairs = float((cnt * nb27).sum())  # candidate pairs: every body against the bodies of its 27 cells
     flops = 20.0 * pairs
-    return {"kernel": "hash_cell_force_kernel<false,2> (wave per cell)" if n_cells_dense(cnt) else "hash_force_kernel",
+    return {"kernel": ("hash_cell_force_kernel<false,2,...,FILTER=true> (wave per cell, two targets per lane, window filtered by the "
+                       "box of the targets)") if n_cells_dense(cnt) else "hash_force_kernel",
             "bound": "valu", "achieved": flops / t / 1e12, "peak": 157.3,
             "unit": "TFLOP/s", "frac": flops / t / 157.3e12, "traffic": None, "avg_kernel_ms": t * 1e3,
             "candidate_pairs_per_s": pairs / t, "gather_bytes_per_s": 16.0 * pairs / t,
-            "issue": read_pmc_issue("r03_pmc_hash_cell_kernel.json"),
+            "issue": read_pmc_issue("r04_pmc_hash_cell_kernel.json") or read_pmc_issue("r03_pmc_hash_cell_kernel.json"),
             "note": "20 flop per candidate pair (distance + cutoff test + force); 16 B per candidate pair is the "
                     "SURVEY 8d gather figure, served from LDS tiles (HBM traffic is 28 B per body)"}
 
@@ -480,7 +539,10 @@ def main():
     os.dup2(2, 1)
     if (int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1
             and not a.no_cpu_baseline and not ClockSampler.under_profiler()):
-        prepare_cpu_oracle()  # the only child process of a run, started before the GPU is initialised
+        prepare_cpu_oracle()  # (child processes of a run are started here, before the GPU is initialised)
+    if (a.pmc and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.workload == "direct" and not a.force_sharded
+            and not ClockSampler.under_profiler()):
+        collect_pmc_traffic(a)
     import torch
     import torch.distributed as dist
 
@@ -696,8 +758,10 @@ def main():
         out["roofline"] = {
             "kernel": kname, "bound": "valu", "achieved": achieved,
             "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-            "traffic": read_pmc_traffic() if world == 1 else None,
-            "traffic_source": "profiles/pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over this command",
+            "traffic": ((_PMC_MEASURED["hbm_bytes_per_launch"] if _PMC_MEASURED else read_pmc_traffic()) if world == 1 else None),
+            "traffic_source": (_PMC_MEASURED["source"] if _PMC_MEASURED else
+                               "profiles/pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes over "
+                               "this command (committed; `bench.py --pmc` measures it in the run itself)"),
             "launch_ms": ms, "pairs_per_launch": pairs, "flop_per_pair": FLOP_PER_PAIR,
             "direct_info": (ctx.directInfo(n, eps2) if world == 1 else None),
             "pair_interactions_per_s_kernel": pairs / (ms * 1e-3),
@@ -710,6 +774,18 @@ def main():
                     "its executed flop count is lower.  launch_ms = event mean over the kernel + its "
                     "finalize epilogue",
         }
+        if world == 1 and info["kernel"] > 0:
+            # what the kernel EXECUTES beside the algorithmic figure: each unordered pair once, 18 (equal masses) / 20
+            # (general masses) fp32 lane-slots per pair -- a packed instruction is two lane-slots -- against the packed
+            # issue rate 1024 SIMDs x 64 lanes x 2 slots / 4 cycles at the clock sampled beside the timed steps
+            slots = 18.0 if eqm else 20.0
+            clk_hz = (clock["sclk_mhz_median"] if clock else 2400.0) * 1e6
+            rate = 1024.0 * 64.0 * 2.0 / 4.0 * clk_hz
+            out["roofline"]["executed"] = {
+                "lane_slots_per_unordered_pair": slots, "unordered_pairs_per_launch": pairs / 2.0,
+                "lane_slots_per_s": slots * pairs / 2.0 / (ms * 1e-3), "packed_issue_rate_lane_slots_per_s": rate,
+                "frac": slots * pairs / 2.0 / (ms * 1e-3) / rate,
+                "clock_mhz": clk_hz / 1e6, "clock_source": "sampled beside the timed steps" if clock else "nominal 2400 MHz (no sample)"}
         if clock:
             # the same fraction against the FP32 peak at the clock the chip actually sustained (peak is quoted at 2.4 GHz)
             clock["frac_at_sustained_clock"] = out["roofline"]["frac"] * 2400.0 / clock["sclk_mhz_median"]

@@ -48,6 +48,9 @@
 #ifndef NBH_HASH_RADIX_BITS
 #define NBH_HASH_RADIX_BITS 10
 #endif
+#ifndef NBH_HASH_SPLIT_CNT
+#define NBH_HASH_SPLIT_CNT 6
+#endif
 #ifndef NBH_HASH_OWN_SORT
 #define NBH_HASH_OWN_SORT 1   // 0: rocprim::radix_sort_pairs everywhere (A/B builds)
 #endif
@@ -672,9 +675,12 @@ struct CellTargets<GUARD, 1> {
 // wave's cells pays the global-memory latency of its lookups.
 constexpr int kCellsPerWave = 4;
 constexpr double kFilterFrom = 40.0;  // bodies per cell from which the filtered form pays when cutoff > cell (see FILTER below)
-constexpr double kFilterFromInside = 8.0;  // ... and when cutoff <= cell: with the compare-free decision (round 4) the box test
-                                           // pays from the density the two-targets-per-lane form starts at (0.95 against 0.99 ms at
-                                           // 15 per cell, 0.67 against 0.97 ms at cutoff = cell / 2: profiles/r04_hash_kernels.txt)
+constexpr double kBodyBelow = 8.0;   // bodies per cell below which one lane takes one body (hash_body_force_kernel)
+constexpr int kSplitFrom = 500000;   // bodies from which the automatic form below kBodyBelow is the split one
+constexpr int kSplitCnt = NBH_HASH_SPLIT_CNT;  // ... except the bodies of cells this crowded: wave per cell (split form)
+constexpr double kFilterFromInside = 13.0;  // ... and when cutoff <= cell: with the compare-free decision (round 4) the box test
+                                           // pays from ~13 per cell (0.96 against 0.99 ms at 15 per cell, 0.98 against 0.91 ms
+                                           // at 11, 0.67 against 0.97 ms at cutoff = cell / 2: profiles/r04_hash_kernels.txt)
 
 // A grid as the force kernel sees it.  lb covers the cells [base, base + count] of the (global) grid --
 // the whole grid, or the z-slab a rank holds (sharded path); cells outside hold no bodies of this grid.
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
     float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
     const int2* __restrict__ units = nullptr, const int* __restrict__ unit_count = nullptr,
-    int* __restrict__ unit_count_host = nullptr, int unit_capacity = 0) {
+    int* __restrict__ unit_count_host = nullptr, int unit_capacity = 0, int crowded_only = 0) {
   constexpr int KC = kCellsPerWave;
   __shared__ float4 win_all[4][kWinCap];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -742,6 +748,8 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       unit_count_host[0] = n_units;
       unit_count_host[1] = unit_count[1];
     }
+    // split form (launch_cell_forces kern 9): without a crowded cell the one-lane-per-body kernel has taken every body
+    if (crowded_only && __builtin_amdgcn_readfirstlane(unit_count[1]) == 0) return;
     // the list front to back in workgroup order (heavy units first, see cell_units_kernel)
     grp = (int)blockIdx.x * 4 + w;
     grp_end = (n_units + KC - 1) / KC;
@@ -1369,6 +1377,115 @@ __global__ __launch_bounds__(kBlock) void layer_export_kernel(const float4* __re
   for (int c = blockIdx.x * kBlock + threadIdx.x; c <= layer_cells; c += stride) lb_out[c] = lb_layer[c] - first;
 }
 
+// ---------------------------------------------------------------------------------------
+// ONE LANE PER BODY (round 4; nbody_hip_grid_tuning 8, and the light cells of a clumped sparse grid).  The wave-per-cell
+// kernels pay ~400 instructions of lookups, window staging and slice reduction per cell: the right price for a cell of
+// 15 bodies and a window of 400 entries, 10x the pair work for a cell of one or two bodies in a thin neighbourhood --
+// and a uniform box that has expanded and clumped (config 5 a few thousand steps in) is 1.1 M occupied cells of which
+// 0.9 M hold one to four bodies.  Here a lane takes one body, looks its nine runs up itself and walks them entry by
+// entry straight from the cell-ordered list (L1 / L2: neighbouring lanes are neighbouring bodies and read the same
+// lines); no LDS, no cross-lane step.  Same pair set, same per-pair arithmetic; fp32 partial sums of <= 32 entries
+// folded into fp64, in window order.
+// ---------------------------------------------------------------------------------------
+template <bool GUARD>
+__global__ __launch_bounds__(kBlock) void hash_body_force_kernel(
+    const CellGridView tgv, const CellGridView sgv, const unsigned int* __restrict__ tkeys, long long cell_first,
+    long long cell_end, int gx, int gy, int gz, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
+    float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
+    const int* __restrict__ light, const int* __restrict__ light_count) {
+  // the targets: the bodies of the cells [cell_first, cell_end) = one contiguous range of the cell-ordered list (the grid
+  // is launched for every body the target grid holds; the threads beyond the range leave) -- or, in the split form, the
+  // bodies whose sorted positions cell_units_kernel listed (those of the cells below kSplitCnt bodies)
+  const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+  int t;
+  // (light_count[-2] = bodies of the most crowded cell if above 64, else 0: cell_units_kernel.  No crowded cell: there is
+  // nothing for the wave-per-cell kernel to take, every body is listed... so the list is skipped: the range itself)
+  if (light && light_count[-2] != 0) {
+    if (i >= *light_count) return;
+    t = light[i];
+  } else {
+    t = tgv.lower(cell_first) + i;
+    if (t >= tgv.lower(cell_end)) return;
+  }
+  const unsigned int c32 = tkeys[t], layer = (unsigned int)gx * (unsigned int)gy;
+  const float4 p = tgv.sorted[t];
+  const unsigned int uz = c32 / layer, rem = c32 - uz * layer, uy = rem / (unsigned int)gx;
+  const int cx = (int)(rem - uy * (unsigned int)gx), cy = (int)uy, cz = (int)uz;
+  const float4* __restrict__ sorted = sgv.sorted;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  f2 ax = (f2)(0.f), ay = ax, az = ax;
+  int run = 0;  // entries in the current fp32 partial sums
+  [[maybe_unused]] f2 nbig, kk;
+  if constexpr (!GUARD) {
+    const CutConst c = cut_const(cutoff2);
+    nbig = (f2)(c.nbig);
+    kk = (f2)(c.k);
+  }
+  for (int r = 0; r < 9; r++) {
+    const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+    if (yy < 0 || yy >= gy || zz < 0 || zz >= gz) continue;
+    const long long base = ((long long)zz * gy + yy) * gx;
+    const int k0 = sgv.lower(base + max(cx - 1, 0)), k1 = sgv.lower(base + min(cx + 2, gx));
+    if constexpr (GUARD) {
+      for (int k = k0; k < k1; k++) {
+        const float4 e = sorted[k];
+        const float dx = e.x - p.x, dy = e.y - p.y, dz = e.z - p.z;
+        const float d2 = hash_dist2(dx, dy, dz);
+        const float inv = __builtin_amdgcn_rsqf(d2 + eps2);
+        const bool ok = (d2 < cutoff2) && (d2 > 0.f);  // :131, unsoftened distance; coincident / self: contributes 0
+        const float f = ok ? (e.w * inv) * (inv * inv) : 0.f;
+        ax.x = __builtin_fmaf(f, dx, ax.x);
+        ay.x = __builtin_fmaf(f, dy, ay.x);
+        az.x = __builtin_fmaf(f, dz, az.x);
+        if (++run == 32) {
+          sx += (double)ax.x; sy += (double)ay.x; sz += (double)az.x;
+          ax = ay = az = (f2)(0.f);
+          run = 0;
+        }
+      }
+    } else {
+      // two entries a round in the halves of packed instructions (the compare-free cutoff decision of CellTargets); an
+      // odd run ends with its last entry twice, the copy with mass 0
+      for (int k = k0; k < k1; k += 2) {
+        const float4 e0 = sorted[k];
+        float4 e1 = sorted[min(k + 1, k1 - 1)];
+        if (k + 1 >= k1) e1.w = 0.f;
+        const f2 dx = f2{e0.x, e1.x} - (f2)(p.x), dy = f2{e0.y, e1.y} - (f2)(p.y), dz = f2{e0.z, e1.z} - (f2)(p.z);
+        const f2 d2 = hash_dist2(dx, dy, dz);
+        const f2 de = d2 + (f2)(eps2);
+        f2 inv;
+        inv.x = __builtin_amdgcn_rsqf(de.x);
+        inv.y = __builtin_amdgcn_rsqf(de.y);
+        f2 tt;  // 1 where d2 < cutoff^2, else 0
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(tt) : "v"(d2), "v"(nbig), "v"(kk));
+        const f2 f = (inv * (tt * f2{e0.w, e1.w})) * (inv * inv);
+        ax = __builtin_elementwise_fma(f, dx, ax);
+        ay = __builtin_elementwise_fma(f, dy, ay);
+        az = __builtin_elementwise_fma(f, dz, az);
+        run += 2;
+        if (run >= 32) {  // (the two halves are the even and the odd entries of <= 32: 16 terms each)
+          sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
+          ax = ay = az = (f2)(0.f);
+          run = 0;
+        }
+      }
+    }
+  }
+  sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
+  const int o = tgv.idx[t];
+  const float ox = (float)((double)G * sx), oy = (float)((double)G * sy), oz = (float)((double)G * sz);
+  if (acc4) {
+    if (accumulate) {
+      const float4 q = acc4[o];
+      acc4[o] = make_float4(q.x + ox, q.y + oy, q.z + oz, 0.f);
+    } else {
+      acc4[o] = make_float4(ox, oy, oz, 0.f);
+    }
+  } else {
+    acc_x[o] = ox; acc_y[o] = oy; acc_z[o] = oz;
+  }
+}
+
 // z cell coordinate of every body on a given grid (slab assignment of the sharded path)
 __global__ __launch_bounds__(kBlock) void cell_z_kernel(const float4* __restrict__ posm, int n,
                                                         float lo_z, float cell, int gz,
@@ -1514,6 +1631,7 @@ struct nbody_hip_grid {
   // the previous lists' lengths in mapped host memory (they size the next launch; a stale value costs time, not results)
   int2* d_units = nullptr;
   size_t units_cap = 0;
+  int* d_light = nullptr;              // split form: sorted positions of the bodies of the light cells (max_particles ints)
   int* d_unit_count = nullptr;         // [2][4]: {heavy units, bodies of the most crowded cell, other units, -}, alternating
   int* h_unit_hint = nullptr;          // pinned [2][4]: {units, most crowded cell, sequence word, -} for whole-range calls /
                                        // layer-range calls
@@ -1521,6 +1639,8 @@ struct nbody_hip_grid {
   unsigned unit_flip = 0;
   unsigned stat_tick = 0;
   int stat_seq = 0;
+  int split_cnt = kSplitCnt;           // split form: cells from this many bodies take the wave-per-cell kernel (NBH_HASH_SPLIT_CNT
+                                       // in the environment at creation: A/B runs)
   double filter_from_inside = kFilterFromInside;  // bodies per cell from which the filtered form runs when cutoff <= cell
                                        // (NBH_HASH_FILTER_FROM in the environment at creation: A/B runs)
   int use_units = 1;                   // NBH_HASH_UNITS in the environment at creation: 0 = never (the cell-range form,
@@ -1530,7 +1650,7 @@ struct nbody_hip_grid {
   long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
   int slab_z0 = 0, slab_nz = 0;         // packed builds: z layers this grid holds (nz <= 0: all)
   int tune_kernel = 0;                 // 0 automatic, 1 cell-run kernel, 2 / 3 / 4 wave-per-cell kernel with R = 1 / 2 / 4,
-                                       // 5 = half-shell TIMING PROBE (not forces), 6 = filtered form, 7 = two-phase form
+                                       // 5 = half-shell TIMING PROBE (not forces), 6 = filtered form, 7 = two-phase form, 8 = one lane per body, 9 = split: one lane per body / wave per crowded cell
   bool ranges_valid = false;
   // host mirror of the last build
   GridInfo info{};
@@ -1543,6 +1663,7 @@ static void grid_release(nbody_hip_grid* g) {
   (void)hipFree(g->d_keys_b); (void)hipFree(g->d_idx_b);
   (void)hipFree(g->d_sorted); (void)hipFree(g->d_sort_tmp); (void)hipFree(g->d_hist); (void)hipFree(g->d_cell_start);
   (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb); (void)hipFree(g->d_units); (void)hipFree(g->d_unit_count);
+  (void)hipFree(g->d_light);
   if (g->h_unit_hint) (void)hipHostFree(g->h_unit_hint);
   if (g->h_info) (void)hipHostFree(g->h_info);
   delete g;
@@ -1594,6 +1715,10 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
         }
         const char* env = std::getenv("NBH_HASH_UNITS");
         g->use_units = env && env[0] == '0' ? 0 : (env && env[0] == '2' ? 2 : 1);
+        if (const char* sc = std::getenv("NBH_HASH_SPLIT_CNT")) {
+          const int v = std::atoi(sc);
+          if (v >= 2) g->split_cnt = v;
+        }
         if (const char* ff = std::getenv("NBH_HASH_FILTER_FROM")) {
           const double v = std::atof(ff);
           if (v > 0.0) g->filter_from_inside = v;
@@ -1628,7 +1753,7 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
 }
 extern "C" int nbody_hip_grid_tuning(nbody_hip_grid* g, int kernel) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
-  if (kernel < 0 || kernel > 7) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..7");
+  if (kernel < 0 || kernel > 9) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..9");
   g->tune_kernel = kernel;
   return NBODY_HIP_OK;
 }
@@ -1830,29 +1955,54 @@ constexpr int kUnitCells = 8;  // consecutive cells per thread (one slot-range a
 // hardware starts workgroups in index order, so the long units run first and the short ones fill the tail (longest
 // processing time first; with the plain cell order a clump late in the list left the chip waiting for it).
 constexpr int kHeavyCell = 48;
+// BODIES (the split form, launch_cell_forces kern 9): the cells below min_cnt bodies make no units; their bodies' sorted
+// positions go to the list `light` instead (count[3] = its length), for hash_body_force_kernel -- one lane per body, in
+// full waves.  (The order of the list does not reach the results: a lane's sum involves no other lane.)
+template <bool BODIES>
 __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView tgv, long long cell_first, long long cell_end,
                                                             int chunk, int2* __restrict__ units, int capacity,
-                                                            int* __restrict__ count, int* __restrict__ count_next) {
+                                                            int* __restrict__ count, int* __restrict__ count_next,
+                                                            int min_cnt, int* __restrict__ light) {
   // count[0]: heavy units, count[1]: bodies of the most crowded cell, count[2]: the other units (the host reads the
-  // sum and the maximum, one call late, to choose the kernel form and to size its grid)
-  __shared__ int wsum[2][kBlock / 64], wmax[kBlock / 64];
-  __shared__ int base_s[2];
+  // sum and the maximum, one call late, to choose the kernel form and to size its grid), count[3]: bodies in `light`
+  __shared__ int wsum[3][kBlock / 64], wmax[kBlock / 64];
+  __shared__ int base_s[3];
   const long long i0 = ((long long)blockIdx.x * kBlock + threadIdx.x) * kUnitCells;
-  if (i0 == 0) { count_next[0] = 0; count_next[1] = 0; count_next[2] = 0; }
+  if (i0 == 0) { count_next[0] = 0; count_next[1] = 0; count_next[2] = 0; count_next[3] = 0; }
   int nus[kUnitCells];
-  int nu[2] = {0, 0};  // light, heavy
+  [[maybe_unused]] int lpos[kUnitCells], lcnt[kUnitCells];
+  int nu[3] = {0, 0, 0};  // light units, heavy units, bodies for the list
   int mx = 0;
   unsigned heavy_mask = 0;
   {
-    int lo = cell_first + i0 < cell_end ? tgv.lower(cell_first + i0) : 0;
+    // the thread's nine start-array entries: two 16-byte loads and one word where the eight cells lie inside the array
+    // and on a 16-byte boundary (the whole-grid call: always), nine clamped word loads otherwise
+    int lbv[kUnitCells + 1];
+    const long long k0 = cell_first + i0 - tgv.base;
+    static_assert(kUnitCells == 8, "two int4 loads");
+    if (cell_first + i0 + kUnitCells <= cell_end && k0 >= 0 && k0 + kUnitCells <= tgv.count && (k0 & 3) == 0) {
+      const int4 a = *reinterpret_cast<const int4*>(tgv.lb + k0), b = *reinterpret_cast<const int4*>(tgv.lb + k0 + 4);
+      lbv[0] = a.x; lbv[1] = a.y; lbv[2] = a.z; lbv[3] = a.w; lbv[4] = b.x; lbv[5] = b.y; lbv[6] = b.z; lbv[7] = b.w;
+      lbv[8] = tgv.lb[k0 + 8];
+    } else {
+#pragma unroll
+      for (int k = 0; k <= kUnitCells; k++) lbv[k] = cell_first + i0 + k <= cell_end ? tgv.lower(cell_first + i0 + k) : 0;
+    }
+    int lo = lbv[0];
 #pragma unroll
     for (int k = 0; k < kUnitCells; k++) {
       nus[k] = 0;
+      if constexpr (BODIES) lcnt[k] = 0;
       if (cell_first + i0 + k < cell_end) {
-        const int hi = tgv.lower(cell_first + i0 + k + 1);
+        const int hi = lbv[k + 1];
         const int cnt = hi - lo;
+        nus[k] = cnt >= min_cnt ? (cnt + chunk - 1) / chunk : 0;
+        if constexpr (BODIES) {
+          lpos[k] = lo;
+          lcnt[k] = cnt < min_cnt ? cnt : 0;
+          nu[2] += lcnt[k];
+        }
         lo = hi;
-        nus[k] = (cnt + chunk - 1) / chunk;
         const int h = cnt > kHeavyCell ? 1 : 0;
         heavy_mask |= (unsigned)h << k;
         nu[h] += nus[k];
@@ -1862,26 +2012,30 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-  int incl[2] = {nu[0], nu[1]};
+  int incl[3] = {nu[0], nu[1], nu[2]};
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int u0 = __shfl_up(incl[0], off, 64), u1 = __shfl_up(incl[1], off, 64);
-    if ((int)(threadIdx.x & 63) >= off) { incl[0] += u0; incl[1] += u1; }
+    int u2 = 0;
+    if constexpr (BODIES) u2 = __shfl_up(incl[2], off, 64);
+    if ((int)(threadIdx.x & 63) >= off) { incl[0] += u0; incl[1] += u1; incl[2] += u2; }
   }
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 63) { wsum[0][wv] = incl[0]; wsum[1][wv] = incl[1]; wmax[wv] = mx; }
+  if ((threadIdx.x & 63) == 63) { wsum[0][wv] = incl[0]; wsum[1][wv] = incl[1]; wsum[2][wv] = incl[2]; wmax[wv] = mx; }
   __syncthreads();
-  int before[2] = {0, 0}, total[2] = {0, 0}, bmax = 0;
+  int before[3] = {0, 0, 0}, total[3] = {0, 0, 0}, bmax = 0;
 #pragma unroll
   for (int k = 0; k < kBlock / 64; k++) {
-    if (k < wv) { before[0] += wsum[0][k]; before[1] += wsum[1][k]; }
+    if (k < wv) { before[0] += wsum[0][k]; before[1] += wsum[1][k]; before[2] += wsum[2][k]; }
     total[0] += wsum[0][k];
     total[1] += wsum[1][k];
+    total[2] += wsum[2][k];
     bmax = max(bmax, wmax[k]);
   }
   if (threadIdx.x == 0) {
     base_s[1] = total[1] ? atomicAdd(count, total[1]) : 0;
     base_s[0] = total[0] ? atomicAdd(count + 2, total[0]) : 0;
+    base_s[2] = (BODIES && total[2]) ? atomicAdd(count + 3, total[2]) : 0;
     if (bmax > 64) atomicMax(count + 1, bmax);  // (only crowded cells matter: most workgroups skip the atomic)
   }
   __syncthreads();
@@ -1894,6 +2048,12 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
       const int slot = h ? a : capacity - 1 - a;  // heavy: from the front; light: from the back
       if (slot >= 0 && slot < capacity) units[slot] = make_int2((int)(i0 + k), q);
     }
+  }
+  if constexpr (BODIES) {
+    int lat = base_s[2] + before[2] + incl[2] - nu[2];
+#pragma unroll
+    for (int k = 0; k < kUnitCells; k++)
+      for (int q = 0; q < lcnt[k]; q++) light[lat++] = lpos[k] + q;
   }
 }
 // the list's statistics for the host when the force kernel that follows is not the unit form (which exports them itself)
@@ -1913,7 +2073,7 @@ __global__ void cell_units_export_kernel(const int* __restrict__ count, int* __r
 
 // the work list of the cells [cell_first, cell_end) of grid gt (see cell_units_kernel); *cur: its two counters
 static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGridView& tv, long long cell_first,
-                          long long cell_end, int chunk, int** cur_out) {
+                          long long cell_end, int chunk, int** cur_out, int min_cnt = 1, bool bodies = false) {
   const size_t nb = gt->built_count;
   const size_t need = nb + nb / 64 + 1024;  // an occupied cell is at least one unit; chunks hold >= 64 bodies
   if (need > gt->units_cap) {
@@ -1929,8 +2089,15 @@ static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGrid
   int* next = gt->d_unit_count + 4 * ((gt->unit_flip + 1) & 1);
   gt->unit_flip++;
   const long long cells = cell_end - cell_first;
-  hipLaunchKernelGGL(cell_units_kernel, dim3((unsigned)((cells + kBlock * kUnitCells - 1) / (kBlock * kUnitCells))), dim3(kBlock), 0, ctx->stream, tv,
-                     cell_first, cell_end, chunk, gt->d_units, (int)gt->units_cap, cur, next);
+  const dim3 ugrid((unsigned)((cells + kBlock * kUnitCells - 1) / (kBlock * kUnitCells)));
+  if (bodies) {
+    if (!gt->d_light) NBH_HIP(hipMalloc(reinterpret_cast<void**>(&gt->d_light), gt->max_particles * sizeof(int)));
+    hipLaunchKernelGGL(cell_units_kernel<true>, ugrid, dim3(kBlock), 0, ctx->stream, tv, cell_first, cell_end, chunk, gt->d_units,
+                       (int)gt->units_cap, cur, next, min_cnt, gt->d_light);
+  } else {
+    hipLaunchKernelGGL(cell_units_kernel<false>, ugrid, dim3(kBlock), 0, ctx->stream, tv, cell_first, cell_end, chunk, gt->d_units,
+                       (int)gt->units_cap, cur, next, min_cnt, nullptr);
+  }
   NBH_LAUNCH_CHECK();
   *cur_out = cur;
   return NBODY_HIP_OK;
@@ -1941,6 +2108,48 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
                               float eps2, float G, float* ax, float* ay, float* az, float4* acc4, int accumulate,
                               nbody_hip_grid* gt = nullptr, int hint_slot = 0, int* prebuilt = nullptr) {
   if (cell_end <= cell_first) return NBODY_HIP_OK;
+  if (kern == 8 || kern == 9) {
+    // 8: one lane per body for every body.  9 (the automatic form below kBodyBelow bodies per cell), SPLIT by cell: bodies
+    // of cells with fewer than kSplitCnt bodies take one lane each; the cells of kSplitCnt and more -- the clumps of a
+    // box that has clumped: cells of hundreds of bodies and windows of a thousand entries -- go on a work list and the
+    // wave-per-cell kernel (two targets per lane) takes them.  The split is a function of the cell alone, so the result
+    // is a function of the input alone; the list's length reaches the host one call late and only sizes the launch.
+    if (!gt) return NBH_FAIL(NBODY_HIP_ERR_STATE, "the one-lane-per-body kernel needs the target grid");
+    const bool split = kern == 9 && cell_end - cell_first < 0x7fffffffLL;  // (NBH_HASH_UNITS does not reach this: it
+                                                                           // chooses between two bit-identical forms, this is a kernel shape)
+    const unsigned blocks = (unsigned)((gt->built_count + kBlock - 1) / kBlock);
+    int* cur = nullptr;
+    if (split)  // the crowded cells' units and the light cells' bodies, one pass over the cells
+      if (int rc = make_unit_list(ctx, gt, tv, cell_first, cell_end, 128, &cur, gt->split_cnt, true)) return rc;
+    const int* light = split ? gt->d_light : nullptr;
+    const int* light_count = split ? cur + 3 : nullptr;
+    if (guard)
+      hipLaunchKernelGGL((hash_body_force_kernel<true>), dim3(blocks), dim3(kBlock), 0, ctx->stream, tv, sv, gt->d_keys_b,
+                         cell_first, cell_end, gx, gy, gz, cutoff2, eps2, G, ax, ay, az, acc4, accumulate, light, light_count);
+    else
+      hipLaunchKernelGGL((hash_body_force_kernel<false>), dim3(blocks), dim3(kBlock), 0, ctx->stream, tv, sv, gt->d_keys_b,
+                         cell_first, cell_end, gx, gy, gz, cutoff2, eps2, G, ax, ay, az, acc4, accumulate, light, light_count);
+    NBH_LAUNCH_CHECK();
+    if (!split) return NBODY_HIP_OK;
+    int* uhint = gt->h_unit_hint_dev ? gt->h_unit_hint_dev + 4 * hint_slot : nullptr;
+    const int hint = uhint ? gt->h_unit_hint[4 * hint_slot] : 0;
+    const long long bound = (long long)gt->built_count / gt->split_cnt + (long long)gt->built_count / 128 + 1;
+    long long est = hint > 0 ? (long long)hint + hint / 64 + 64 : 4096;  // (first call: a guess; the kernel strides)
+    if (est > bound) est = bound;
+    long long ublocks = (est + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
+    if (ublocks < 8) ublocks = 8;
+    const int uper = (int)((ublocks + 7) / 8);
+    if (guard)
+      hipLaunchKernelGGL((hash_cell_force_kernel<true, 2, false, true>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
+                         tv, sv, gx, gy, gz, cell_first, cell_end, uper, cutoff2, eps2, G, ax, ay, az, acc4, accumulate,
+                         gt->d_units, cur, uhint, (int)gt->units_cap, 1);
+    else
+      hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, false, true>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
+                         tv, sv, gx, gy, gz, cell_first, cell_end, uper, cutoff2, eps2, G, ax, ay, az, acc4, accumulate,
+                         gt->d_units, cur, uhint, (int)gt->units_cap, 1);
+    NBH_LAUNCH_CHECK();
+    return NBODY_HIP_OK;
+  }
   const long long nblk = (cell_end - cell_first + 4 * kCellsPerWave - 1) / (4 * kCellsPerWave);
   int per_xcd = (int)((nblk + 7) / 8);
   // The unit list (occupied cells in chunks of 64 R bodies) is what the kernel takes when the previous call of this
@@ -2070,32 +2279,24 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
   //   cells (> 64 bodies: a box that has expanded and clumped -- mean 0.2 bodies per cell, cells of 300 beside a
   //   majority of empty ones) take the wave-per-cell kernel over that list (3.5 ms against 4.9 ms), an evenly sparse
   //   grid takes the cell-run kernel (0.16 against 0.26 ms at 0.9 bodies per cell).
+  //   round 4: below kBodyBelow bodies per cell ONE LANE PER BODY (hash_body_force_kernel) replaces both the wave-per-cell
+  //   form with one body per lane and the cell-run kernel wherever the grid carries start arrays: 0.027 against 0.155 ms
+  //   at 0.9 bodies per cell, 0.142 against 0.329 ms at 3.7, 0.77 against 0.87 ms at 6.6, level at 8.8
+  //   (profiles/r04_hash_kernels.txt) -- and a box that has expanded and clumped (mean 0.2 bodies per cell, 0.9 M cells of
+  //   one to four bodies beside clumps) needs neither a work list nor a read-back of its occupancy any more.
   int* prebuilt = nullptr;
   if (kern == 0) {
     if (!g->lb_valid) {
       kern = 1;
-    } else if (rho >= (strict ? 0.5 : 1.0)) {
-      kern = rho < 8.0 ? 2 : (rho < (strict ? kFilterFrom : g->filter_from_inside) ? 3 : 6);
-    } else if (g->use_units && g->h_unit_hint_dev && g->lb_count < 0x7fffffffLL) {
-      const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
-      if (int rc = make_unit_list(ctx, g, view, g->lb_base, g->lb_base + g->lb_count, 64, &prebuilt)) return rc;
-      const int seq = ++g->stat_seq;
-      hipLaunchKernelGGL(cell_units_export_kernel, dim3(1), dim3(64), 0, ctx->stream, prebuilt, g->h_unit_hint_dev, seq);
-      NBH_LAUNCH_CHECK();
-      const volatile int* word = &g->h_unit_hint[2];
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned spins = 0;
-      while (*word != seq) {
-        if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) break;
-      }
-      if (*word != seq) NBH_HIP(hipStreamSynchronize(ctx->stream));
-      std::atomic_thread_fence(std::memory_order_acquire);
-      kern = g->h_unit_hint[1] > 64 ? 2 : 1;
-      if (kern == 1) prebuilt = nullptr;
+    } else if (rho >= kBodyBelow) {
+      kern = rho < (strict ? kFilterFrom : g->filter_from_inside) ? 3 : 6;
     } else {
-      kern = 1;
+      // (small systems: the list pass and the third launch of the split form are ~10 us, a third of the whole evaluation
+      // at 262,144 bodies; below kSplitFrom bodies every body takes a lane)
+      kern = n >= kSplitFrom ? 9 : 8;
     }
   }
+  if ((kern == 8 || kern == 9) && !g->lb_valid) kern = 1;  // (no start arrays: the cell-run kernel)
   if (kern != 1 && g->lb_valid) {
     const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
     return launch_cell_forces(ctx, view, view, gx, gy, gz, g->lb_base, g->lb_base + g->lb_count, kern, guard, cutoff2,
@@ -2175,7 +2376,7 @@ extern "C" int nbody_hip_grid_forces_pair_packed(nbody_hip_grid* gt, nbody_hip_g
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
   const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
   int kern = gt->tune_kernel;
-  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < (cutoff > gt->cell_size ? kFilterFrom : gt->filter_from_inside) ? 3 : 6);
+  if (kern < 2) kern = rho < kBodyBelow ? (gt->built_count >= (size_t)kSplitFrom ? 9 : 8) : (rho < (cutoff > gt->cell_size ? kFilterFrom : gt->filter_from_inside) ? 3 : 6);
   const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
   const CellGridView sv{gs->d_sorted, gs->d_cell_lb, gs->d_idx_b, gs->lb_base, gs->lb_count};
   return launch_cell_forces(ctx, tv, sv, gx, gy, gz, c0, c1, kern, eps2 < 1e-12f || !cut_const_ok(cutoff2), cutoff2, eps2, G, nullptr, nullptr,
@@ -2222,7 +2423,7 @@ extern "C" int nbody_hip_grid_forces_layer_packed(nbody_hip_grid* gt, int z, con
   const float eps2 = eps * eps, cutoff2 = cutoff * cutoff;
   const double rho = (double)gt->built_count / (double)(gt->lb_count > 0 ? gt->lb_count : 1);
   int kern = gt->tune_kernel;
-  if (kern < 2) kern = rho < 8.0 ? 2 : (rho < (cutoff > gt->cell_size ? kFilterFrom : gt->filter_from_inside) ? 3 : 6);
+  if (kern < 2) kern = rho < kBodyBelow ? (gt->built_count >= (size_t)kSplitFrom ? 9 : 8) : (rho < (cutoff > gt->cell_size ? kFilterFrom : gt->filter_from_inside) ? 3 : 6);
   const CellGridView tv{gt->d_sorted, gt->d_cell_lb, gt->d_idx_b, gt->lb_base, gt->lb_count};
   // the source layer as the sender exported it (nbody_hip_grid_export_layer): cells outside it hold nothing
   const CellGridView sv{reinterpret_cast<const float4*>(src_bodies), src_lb, nullptr, (long long)src_z * layer, layer};

@@ -50,3 +50,12 @@ for upto in (0, 250, 1000, 2000, 4000):
     print(f"after {upto:5d} steps: {ms:7.3f} ms/step; grid {gx}x{gy}x{gz}; bodies per cell max {cnt.max()}, p99.9 {np.quantile(cnt, 0.999):.0f}, "
           f"mean {cnt.mean():.1f}; candidate pairs {pairs:.3e} ({pairs / n:.0f} per body); heaviest cell {per_cell.max():.3e} pairs = "
           f"{per_cell.max() / pairs * 100:.2f} % of all; cells above 128 bodies: {(cnt > 128).sum()}", flush=True)
+    # who holds the bodies, the units (one wave pass each in the wave-per-cell kernel) and the candidate pairs: by occupancy
+    edges = [1, 2, 3, 5, 9, 17, 33, 65, 129, 1 << 30]
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = (cnt >= lo) & (cnt < hi)
+        if sel.any():
+            win = nb27[sel]
+            print(f"      cells of {lo:3d}-{min(hi - 1, int(cnt.max())):3d} bodies: {int(sel.sum()):8d} cells, {int(cnt[sel].sum()):8d} bodies "
+                  f"({cnt[sel].sum() / n * 100:5.1f} %), {per_cell[sel].sum() / pairs * 100:5.1f} % of the candidate pairs, window mean "
+                  f"{win.mean():6.1f} max {int(win.max())}", flush=True)

@@ -30,7 +30,7 @@ def main():
     torch.cuda.set_device(0)
     cases = [(4194304, 32.0, 1.0, 1.0), (4194304, 32.0, 1.0, 2.0), (1048576, 32.0, 1.0, 1.0),
              (4194304, 32.0, 2.0, 2.0), (262144, 32.0, 1.0, 1.0), (1048576, 16.0, 0.5, 0.5),
-             (4194304, 32.0, 1.0, 0.5), (4194304, 32.0, 1.0, 0.7)]
+             (4194304, 32.0, 1.0, 0.5), (4194304, 32.0, 1.0, 0.7), (1048576, 50.0, 1.0, 1.0), (4194304, 50.0, 1.0, 1.0), (4194304, 42.0, 1.0, 1.0), (4194304, 38.0, 1.0, 1.0), (4194304, 35.0, 1.0, 1.0)]
     for n, half, cell, cutoff in cases:
         ic = nb.ic.uniform_box(n, seed=42, lo=-half, hi=half)
         d, _ = to_device(nb, ic)
@@ -39,7 +39,7 @@ def main():
         rho = n / grid.getTotalCells()
         ref = None
         line = f"N={n} cell={cell} cutoff={cutoff} rho={rho:.2f} build {tb:.3f} ms |"
-        for kern in (1, 2, 3, 4, 6, 7):
+        for kern in (1, 2, 3, 4, 6, 7, 8, 9):
             grid.tuning(kern)
             t = timeit(lambda: grid.computeForces(d, cutoff, 1.0, 0.01))
             a = acc_of(d).astype(np.float64)
