@@ -13,7 +13,7 @@ for n, R, cell, cutoff in ((10000, 10.0, 1.0, 2.0), (100000, 10.0, 1.0, 2.0), (1
     g = nb.SpatialHashGrid(n, cell)
     tb = timeit(lambda: g.build(d))
     line = f"sphere N={n} R={R} cell={cell} cutoff={cutoff} rho_grid={n/g.getTotalCells():.2f} build {tb:.3f} |"
-    for k in (1,2,3):
+    for k in (0, 1, 2, 3, 6, 8, 9):
         g.tuning(k)
         line += f" k{k} {timeit(lambda: g.computeForces(d, cutoff, 1.0, 0.1)):.3f}"
     print(line, flush=True)
