@@ -675,7 +675,7 @@ struct CellTargets<GUARD, 1> {
 // wave's cells pays the global-memory latency of its lookups.
 constexpr int kCellsPerWave = 4;
 constexpr double kFilterFrom = 40.0;  // bodies per cell from which the filtered form pays when cutoff > cell (see FILTER below)
-constexpr double kBodyBelow = 8.0;   // bodies per cell below which one lane takes one body (hash_body_force_kernel)
+constexpr double kBodyBelow = 10.0;   // bodies per cell below which one lane takes one body (hash_body_force_kernel)
 constexpr int kSplitFrom = 500000;   // bodies from which the automatic form below kBodyBelow is the split one
 constexpr int kSplitCnt = NBH_HASH_SPLIT_CNT;  // ... except the bodies of cells this crowded: wave per cell (split form)
 constexpr double kFilterFromInside = 13.0;  // ... and when cutoff <= cell: with the compare-free decision (round 4) the box test
@@ -1444,29 +1444,45 @@ __global__ __launch_bounds__(kBlock) void hash_body_force_kernel(
         }
       }
     } else {
-      // two entries a round in the halves of packed instructions (the compare-free cutoff decision of CellTargets); an
-      // odd run ends with its last entry twice, the copy with mass 0
-      for (int k = k0; k < k1; k += 2) {
-        const float4 e0 = sorted[k];
-        float4 e1 = sorted[min(k + 1, k1 - 1)];
-        if (k + 1 >= k1) e1.w = 0.f;
-        const f2 dx = f2{e0.x, e1.x} - (f2)(p.x), dy = f2{e0.y, e1.y} - (f2)(p.y), dz = f2{e0.z, e1.z} - (f2)(p.z);
-        const f2 d2 = hash_dist2(dx, dy, dz);
-        const f2 de = d2 + (f2)(eps2);
-        f2 inv;
-        inv.x = __builtin_amdgcn_rsqf(de.x);
-        inv.y = __builtin_amdgcn_rsqf(de.y);
-        f2 tt;  // 1 where d2 < cutoff^2, else 0
-        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(tt) : "v"(d2), "v"(nbig), "v"(kk));
-        const f2 f = (inv * (tt * f2{e0.w, e1.w})) * (inv * inv);
-        ax = __builtin_elementwise_fma(f, dx, ax);
-        ay = __builtin_elementwise_fma(f, dy, ay);
-        az = __builtin_elementwise_fma(f, dz, az);
-        run += 2;
-        if (run >= 32) {  // (the two halves are the even and the odd entries of <= 32: 16 terms each)
+      // four entries a round, two and two in the halves of packed instructions (the compare-free cutoff decision of
+      // CellTargets); entries past the end of the run are its last entry again with mass 0.  The fp32 partial sums are
+      // folded into fp64 before they would exceed 64 entries (32 per half), checked once per chunk of a run, not per
+      // round.
+      for (int kc = k0; kc < k1; kc += 32) {
+        const int kend = min(kc + 32, k1);
+        if (run + (kend - kc) > 64) {
           sx += (double)(ax.x + ax.y); sy += (double)(ay.x + ay.y); sz += (double)(az.x + az.y);
           ax = ay = az = (f2)(0.f);
           run = 0;
+        }
+        run += kend - kc;
+        const int klast = kend - 1;
+        for (int k = kc; k < kend; k += 4) {
+          // (32-bit byte offsets from the uniform base: one shift per address instead of 64-bit index arithmetic)
+          const char* sb = reinterpret_cast<const char*>(sorted);
+          const float4 e0 = *reinterpret_cast<const float4*>(sb + ((unsigned)k << 4));
+          float4 e1 = *reinterpret_cast<const float4*>(sb + ((unsigned)min(k + 1, klast) << 4));
+          float4 e2 = *reinterpret_cast<const float4*>(sb + ((unsigned)min(k + 2, klast) << 4));
+          float4 e3 = *reinterpret_cast<const float4*>(sb + ((unsigned)min(k + 3, klast) << 4));
+          if (k + 1 > klast) e1.w = 0.f;
+          if (k + 2 > klast) e2.w = 0.f;
+          if (k + 3 > klast) e3.w = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const float4 ea = h ? e2 : e0, eb = h ? e3 : e1;
+            const f2 dx = f2{ea.x, eb.x} - (f2)(p.x), dy = f2{ea.y, eb.y} - (f2)(p.y), dz = f2{ea.z, eb.z} - (f2)(p.z);
+            const f2 d2 = hash_dist2(dx, dy, dz);
+            const f2 de = d2 + (f2)(eps2);
+            f2 inv;
+            inv.x = __builtin_amdgcn_rsqf(de.x);
+            inv.y = __builtin_amdgcn_rsqf(de.y);
+            f2 tt;  // 1 where d2 < cutoff^2, else 0
+            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(tt) : "v"(d2), "v"(nbig), "v"(kk));
+            const f2 f = (inv * (tt * f2{ea.w, eb.w})) * (inv * inv);
+            ax = __builtin_elementwise_fma(f, dx, ax);
+            ay = __builtin_elementwise_fma(f, dy, ay);
+            az = __builtin_elementwise_fma(f, dz, az);
+          }
         }
       }
     }
