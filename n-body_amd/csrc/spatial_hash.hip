@@ -48,6 +48,9 @@
 #ifndef NBH_HASH_RADIX_BITS
 #define NBH_HASH_RADIX_BITS 10
 #endif
+#ifndef NBH_HASH_SPLIT_FILTER
+#define NBH_HASH_SPLIT_FILTER false  // split form: the crowded cells take the unfiltered two-targets form (the filtered one measured slower there: 1.90 / 1.70 against 1.82 / 1.61 ms at 2,000 / 4,000 steps)
+#endif
 #ifndef NBH_HASH_SPLIT_CNT
 #define NBH_HASH_SPLIT_CNT 6
 #endif
@@ -621,6 +624,10 @@ struct CellTargets {
     px[q >> 1][q & 1] = x; py[q >> 1][q & 1] = y; pz[q >> 1][q & 1] = z;
   }
   __device__ __forceinline__ void pair(const float4 s, float cutoff2, float eps2) {
+#ifdef NBH_PROBE_NO_PAIRS  // timing probe (tools/): everything but the pair arithmetic -- one add keeps the LDS read alive
+    ax[0] += (f2)(s.x);
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       const f2 dx = (f2)(s.x) - px[j], dy = (f2)(s.y) - py[j], dz = (f2)(s.z) - pz[j];
@@ -2156,11 +2163,11 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
     if (ublocks < 8) ublocks = 8;
     const int uper = (int)((ublocks + 7) / 8);
     if (guard)
-      hipLaunchKernelGGL((hash_cell_force_kernel<true, 2, false, true>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((hash_cell_force_kernel<true, 2, false, true, NBH_HASH_SPLIT_FILTER>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
                          tv, sv, gx, gy, gz, cell_first, cell_end, uper, cutoff2, eps2, G, ax, ay, az, acc4, accumulate,
                          gt->d_units, cur, uhint, (int)gt->units_cap, 1);
     else
-      hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, false, true>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, false, true, NBH_HASH_SPLIT_FILTER>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
                          tv, sv, gx, gy, gz, cell_first, cell_end, uper, cutoff2, eps2, G, ax, ay, az, acc4, accumulate,
                          gt->d_units, cur, uhint, (int)gt->units_cap, 1);
     NBH_LAUNCH_CHECK();
