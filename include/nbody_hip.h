@@ -79,12 +79,15 @@ typedef struct nbody_hip_ctx nbody_hip_ctx;
 
 NBODY_HIP_API int nbody_hip_abi_version(void);
 /* Which radix sort bins the bodies (Barnes-Hut build, spatial-hash build; the reference calls thrust::sort_by_key,
- * ref: src/cuda/force_barnes_hut.cu:276-280, force_spatial_hash.cu:286-288).  driver_compiled: 1 when this build holds
- * the library's own driver of rocPRIM's Onesweep kernels (csrc/onesweep.h: only for the rocPRIM version it was tested
- * against, else 0 = the public rocprim::radix_sort_pairs everywhere); self_test: 0 = not run yet (no tree / grid made),
- * 1 = the driver reproduced the public sort word for word in this process, 2 = it did not and is switched off;
- * rocprim_version: ROCPRIM_VERSION of the build.  Any pointer may be NULL. */
-NBODY_HIP_API int nbody_hip_sort_info(int* driver_compiled, int* self_test, int* rocprim_version);
+ * ref: src/cuda/force_barnes_hut.cu:276-280, force_spatial_hash.cu:286-288).  Above the crossover sizes one of
+ *   - the library's driver of rocPRIM's Onesweep kernels (csrc/onesweep.h; compiled only for the rocPRIM version it was
+ *     written against: driver_compiled), the default while its run-time self-test holds (self_test: 0 = not run yet --
+ *     no tree / grid made --, 1 = it reproduced the public sort word for word in this process, 2 = it did not: off);
+ *   - the hand-written sort of csrc/radix_sort.h (no rocPRIM), which runs when the driver is absent or off, or with
+ *     NBH_SORT=own in the environment (own_self_test: the same three states);
+ * below them, with NBH_SORT=public, or when both are off: rocprim::radix_sort_pairs.  rocprim_version: ROCPRIM_VERSION of
+ * the build.  Any pointer may be NULL. */
+NBODY_HIP_API int nbody_hip_sort_info(int* driver_compiled, int* self_test, int* own_self_test, int* rocprim_version);
 NBODY_HIP_API const char* nbody_hip_last_error(void);
 
 /* Number of HIP devices visible (0 when there is no GPU; never fails). */

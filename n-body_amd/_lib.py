@@ -70,7 +70,7 @@ _P = C.c_void_p
 _PD = C.POINTER(ParticleDataStruct)
 PROTOTYPES = {
     "nbody_hip_abi_version": (C.c_int, []),
-    "nbody_hip_sort_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nbody_hip_sort_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nbody_hip_last_error": (C.c_char_p, []),
     "nbody_hip_device_count": (C.c_int, []),
     "nbody_hip_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, _P]),

@@ -37,6 +37,7 @@
 
 #include "common.h"
 #include "onesweep.h"
+#include "radix_sort.h"
 
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                              rocprim::default_config, nbh::kSortMergeLimit>;
@@ -1333,6 +1334,10 @@ struct nbody_hip_tree {
   int capacity = 0;
   unsigned int* d_enc = nullptr;  // two bounding-box buffers of 8 words (see morton_kernel)
   unsigned int* d_hist = nullptr; // two digit-count buffers of the sort (kTreeHistWords each), alternating like d_enc
+  int sort_impl = 0;              // above the crossover: 1 = driver of rocPRIM's Onesweep kernels (onesweep.h, fenced), 2 = the
+                                  // hand-written sort (radix_sort.h), 0 = rocprim::radix_sort_pairs (NBH_SORT in the environment)
+  unsigned int* h_sort_err = nullptr;      // mapped host word the hand-written sort raises when a look-back gives up
+  unsigned int* h_sort_err_dev = nullptr;
   unsigned int enc_flip = 0;
   bool enc_armed = false;
   unsigned long long enc_replays = 0;
@@ -1386,6 +1391,7 @@ static void tree_release(nbody_hip_tree* g) {
                   g->t.first, g->t.last, g->t.child0, g->t.child_last, g->t.rec, g->t.m, g->t.pb,
                   g->d_tmp, g->d_visits, g->d_partial, g->d_prefix, g->d_cost, g->d_order, g->d_bounds};
   for (void* p : ptrs) (void)hipFree(p);
+  if (g->h_sort_err) (void)hipHostFree(g->h_sort_err);
   for (hipEvent_t e : {g->ev_fork, g->ev_join, g->ev_plan})
     if (e) (void)hipEventDestroy(e);
   if (g->side) (void)hipStreamDestroy(g->side);
@@ -1439,14 +1445,32 @@ static int tree_alloc_nodes(nbody_hip_tree* g) {
                                                 static_cast<unsigned int*>(g->d_keys_b), g->d_idx_a, g->d_idx_b, n, 0,
                                                 30, g->ctx->stream);
     g->own_sort_from = own_sort_from(kOwnSortFromTree);
-    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && NBH_BH_OWN_SORT && n >= g->own_sort_from)
-      tree_sort_self_test(g->ctx->stream);  // (once per process: the Onesweep driver against the public sort, onesweep.h)
-    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && onesweep::usable() && n >= g->own_sort_from) {  // the Onesweep driver of our own
-      size_t t2 = 0;
-      e = onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
-          nullptr, t2, static_cast<const unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b),
-          g->d_idx_a, g->d_idx_b, n, 0, 63, g->ctx->stream);
-      if (t2 > t1) t1 = t2;
+    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && n >= g->own_sort_from)
+      tree_sort_self_test(g->ctx->stream);  // (once per process: the driver and the hand-written sort against the public sort)
+    if (e == hipSuccess && g->wide() && NBH_BH_RADIX_BITS > 0 && n >= g->own_sort_from) {  // a radix sort of our own: room for both
+      size_t t2 = 0, t3 = 0;
+      if (onesweep::usable())
+        e = onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
+            nullptr, t2, static_cast<const unsigned long long*>(g->d_keys_a), static_cast<unsigned long long*>(g->d_keys_b),
+            g->d_idx_a, g->d_idx_b, n, 0, 63, g->ctx->stream);
+      if (e == hipSuccess)
+        e = radix::sort_pairs<unsigned long long, false>(nullptr, t3, static_cast<const unsigned long long*>(g->d_keys_a),
+                                                         static_cast<unsigned long long*>(g->d_keys_b), nullptr, nullptr, g->d_idx_a,
+                                                         g->d_idx_b, n, 0, 63, g->ctx->stream, nullptr);
+      t1 = std::max(t1, std::max(t2, t3));
+      const char* env = std::getenv("NBH_SORT");
+      g->sort_impl = (NBH_BH_OWN_SORT && onesweep::usable()) ? 1 : 2;
+      if (env && std::strcmp(env, "own") == 0) g->sort_impl = 2;
+      if (env && std::strcmp(env, "public") == 0) g->sort_impl = 0;
+      if (!g->h_sort_err) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&g->h_sort_err), 64, hipHostMallocMapped) == hipSuccess) {
+          *g->h_sort_err = 0u;
+          if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->h_sort_err_dev), g->h_sort_err, 0) != hipSuccess) g->h_sort_err_dev = nullptr;
+        } else {
+          g->h_sort_err = nullptr;
+        }
+        (void)hipGetLastError();
+      }
     }
     g->tmp_bytes = t1;
     if (e == hipSuccess) e = hipMalloc(&g->d_tmp, g->tmp_bytes > 0 ? g->tmp_bytes : 16);
@@ -1520,9 +1544,9 @@ extern "C" int nbody_hip_tree_create(nbody_hip_ctx* ctx, size_t max_particles, n
 // one buffer through the Onesweep driver and through the public rocprim::radix_sort_pairs, every output word compared.
 // Once per process (the first tree that could take the driver).
 static void tree_sort_self_test(hipStream_t st) {
-#if NBH_BH_OWN_SORT && NBH_ONESWEEP_AVAILABLE && NBH_BH_RADIX_BITS > 0
+#if NBH_BH_RADIX_BITS > 0
   static std::atomic<bool> done{false};
-  if (done.exchange(true) || nbh::onesweep::self_test_state().load(std::memory_order_acquire) == 2) return;
+  if (done.exchange(true)) return;
   const size_t n = 200000;
   const unsigned first_bit = 3, end_bit = 63;  // (a depth-20 build sorts bits 3..62)
   std::vector<unsigned long long> hk(n);
@@ -1533,24 +1557,33 @@ static void tree_sort_self_test(hipStream_t st) {
     hk[i] = (x >> 1) & ~0xfffffull;  // clustered low digits: many equal keys, so that stability shows
     hv[i] = (int)i;
   }
-  unsigned long long *k_in = nullptr, *k_out[2] = {nullptr, nullptr};
-  int *v_in = nullptr, *v_out[2] = {nullptr, nullptr};
+  constexpr int kV = 3;  // 0: the driver, 1: the public sort, 2: the hand-written sort
+  const bool have[kV] = {NBH_BH_OWN_SORT && NBH_ONESWEEP_AVAILABLE, true, true};
+  unsigned long long *k_in = nullptr, *k_out[kV] = {nullptr, nullptr, nullptr};
+  int *v_in = nullptr, *v_out[kV] = {nullptr, nullptr, nullptr};
+  unsigned int *err_h = nullptr, *err_d = nullptr;
   void* tmp = nullptr;
-  size_t t1 = 0, t2 = 0;
-  bool ran = false, same = false;
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  bool ran = false, same[kV] = {false, true, false};
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&k_in), n * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v_in), n * sizeof(int));
-  for (int v = 0; v < 2 && e == hipSuccess; v++) {
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&err_h), 64, hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *err_h = 0u;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&err_d), err_h, 0);
+  }
+  for (int v = 0; v < kV && e == hipSuccess; v++) {
     e = hipMalloc(reinterpret_cast<void**>(&k_out[v]), n * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v_out[v]), n * sizeof(int));
   }
   if (e == hipSuccess) e = rocprim::radix_sort_pairs<SortConfig64>(nullptr, t1, k_in, k_out[1], v_in, v_out[1], n, first_bit, end_bit, st);
-  if (e == hipSuccess) e = onesweep::sort_pairs<NBH_BH_RADIX_BITS>(nullptr, t2, static_cast<const unsigned long long*>(k_in), k_out[0], v_in, v_out[0], n, first_bit, end_bit, st);
-  const size_t tb = t1 > t2 ? t1 : t2;
+  if (e == hipSuccess && have[0]) e = onesweep::sort_pairs<NBH_BH_RADIX_BITS>(nullptr, t2, static_cast<const unsigned long long*>(k_in), k_out[0], v_in, v_out[0], n, first_bit, end_bit, st);
+  if (e == hipSuccess) e = radix::sort_pairs<unsigned long long, false>(nullptr, t3, static_cast<const unsigned long long*>(k_in), k_out[2], nullptr, nullptr, v_in, v_out[2], n, first_bit, end_bit, st, nullptr);
+  const size_t tb = std::max(t1, std::max(t2, t3));
   if (e == hipSuccess) e = hipMalloc(&tmp, tb > 0 ? tb : 16);
   if (e == hipSuccess) e = hipMemcpyAsync(k_in, hk.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(v_in, hv.data(), n * sizeof(int), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) {
+  if (e == hipSuccess && have[0]) {
     size_t b = tb;
     e = onesweep::sort_pairs<NBH_BH_RADIX_BITS>(tmp, b, static_cast<const unsigned long long*>(k_in), k_out[0], v_in, v_out[0], n, first_bit, end_bit, st);
   }
@@ -1559,9 +1592,14 @@ static void tree_sort_self_test(hipStream_t st) {
     e = rocprim::radix_sort_pairs<SortConfig64>(tmp, b, k_in, k_out[1], v_in, v_out[1], n, first_bit, end_bit, st);
   }
   if (e == hipSuccess) {
-    std::vector<unsigned long long> rk[2];
-    std::vector<int> rv[2];
-    for (int v = 0; v < 2 && e == hipSuccess; v++) {
+    size_t b = tb;
+    e = radix::sort_pairs<unsigned long long, false>(tmp, b, static_cast<const unsigned long long*>(k_in), k_out[2], nullptr, nullptr, v_in, v_out[2], n, first_bit, end_bit, st, err_d);
+  }
+  if (e == hipSuccess) {
+    std::vector<unsigned long long> rk[kV];
+    std::vector<int> rv[kV];
+    for (int v = 0; v < kV && e == hipSuccess; v++) {
+      if (!have[v]) continue;
       rk[v].resize(n); rv[v].resize(n);
       e = hipMemcpyAsync(rk[v].data(), k_out[v], n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipMemcpyAsync(rv[v].data(), v_out[v], n * sizeof(int), hipMemcpyDeviceToHost, st);
@@ -1569,15 +1607,20 @@ static void tree_sort_self_test(hipStream_t st) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) {
       ran = true;
-      same = std::memcmp(rk[0].data(), rk[1].data(), n * sizeof(unsigned long long)) == 0 &&
-             std::memcmp(rv[0].data(), rv[1].data(), n * sizeof(int)) == 0;
-      for (size_t i = 1; same && i < n; i++) same = (rk[0][i - 1] >> first_bit) <= (rk[0][i] >> first_bit);
+      bool sorted = true;
+      for (size_t i = 1; sorted && i < n; i++) sorted = (rk[1][i - 1] >> first_bit) <= (rk[1][i] >> first_bit);
+      for (int v = 0; v < kV; v += 2)
+        same[v] = have[v] && sorted && std::memcmp(rk[v].data(), rk[1].data(), n * sizeof(unsigned long long)) == 0 &&
+                  std::memcmp(rv[v].data(), rv[1].data(), n * sizeof(int)) == 0;
+      if (*err_h) same[2] = false;  // (a look-back of the hand-written sort gave up)
     }
   }
   (void)hipGetLastError();
   (void)hipFree(k_in); (void)hipFree(v_in); (void)hipFree(tmp);
-  for (int v = 0; v < 2; v++) { (void)hipFree(k_out[v]); (void)hipFree(v_out[v]); }
-  nbh::onesweep::self_test_report(ran && same, "Barnes-Hut (64-bit keys, index payload)");
+  if (err_h) (void)hipHostFree(err_h);
+  for (int v = 0; v < kV; v++) { (void)hipFree(k_out[v]); (void)hipFree(v_out[v]); }
+  if (have[0]) nbh::onesweep::self_test_report(ran && same[0], "Barnes-Hut (64-bit keys, index payload)");
+  nbh::radix::self_test_report(ran && same[2], "Barnes-Hut (64-bit keys, index payload)");
 #else
   (void)st;
 #endif
@@ -1638,6 +1681,8 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
   const int blocks = (ni + kBlock - 1) / kBlock;
+  if (g->h_sort_err && *g->h_sort_err)
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "the radix sort of an earlier build gave up in its look-back (csrc/radix_sort.h)");
 
   // two bounding-box buffers alternate: this build's was re-armed by the previous build's morton_kernel
   unsigned int* enc = g->d_enc + 8 * (g->enc_flip & 1);
@@ -1688,11 +1733,15 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     // even-aligned sibling groups are what the pair walk needs: trees it will walk (from kPairFrom bodies, or when that
     // walk form is forced) get them, smaller trees keep plain ids and save three launches
     g->aligned = ni >= kPairFrom || g->tune_form == 2;
-    bool own_sort = false;
+    bool own_sort = false;  // a radix sort of our own (1 = driver, 2 = hand-written): the key kernel counts its digits
+    int impl = 0;
     size_t sort_words = 0;
     if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0) {
-      own_sort = NBH_BH_OWN_SORT && onesweep::usable() && n >= g->own_sort_from;
-      if (own_sort) sort_words = onesweep::clear_words<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(n, (unsigned)first_bit, (unsigned)key_bits);
+      impl = n >= g->own_sort_from ? g->sort_impl : 0;
+      if (impl == 1 && !(NBH_BH_OWN_SORT && onesweep::usable())) impl = 2;
+      if (impl == 2 && (!radix::usable() || !g->h_sort_err_dev)) impl = 0;
+      own_sort = impl != 0;
+      if (impl == 1) sort_words = onesweep::clear_words<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(n, (unsigned)first_bit, (unsigned)key_bits);
     }
     int hist_places = 0;
     if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0)
@@ -1709,10 +1758,14 @@ static int tree_build_packed(nbody_hip_tree* g, float4* posm, size_t n, const nb
     using Cfg = std::conditional_t<sizeof(K) == 8, SortConfig64, SortConfig>;
     // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (no fill launches, onesweep.h)
     if constexpr (sizeof(K) == 8 && NBH_BH_RADIX_BITS > 0) {
-      if (own_sort) {
+      if (impl == 1) {
         NBH_HIP(onesweep::sort_pairs<NBH_BH_RADIX_BITS ? NBH_BH_RADIX_BITS : 8>(
             g->d_tmp, tmp, static_cast<const K*>(ka), kb, g->d_idx_a, g->d_idx_b, n, (unsigned)first_bit, (unsigned)key_bits, st,
             /*cleared=*/true, hist_places ? hist : nullptr, kTreeHistCopies, kTreeHistWords));
+      } else if (impl == 2) {
+        NBH_HIP((radix::sort_pairs<K, false>(g->d_tmp, tmp, static_cast<const K*>(ka), kb, nullptr, nullptr, g->d_idx_a, g->d_idx_b, n,
+                                             (unsigned)first_bit, (unsigned)key_bits, st, g->h_sort_err_dev, hist_places ? hist : nullptr,
+                                             hist_places ? kTreeHistCopies : 1, hist_places ? (unsigned)kTreeHistWords : 0u)));
       } else {
         NBH_HIP(rocprim::radix_sort_pairs<Cfg>(g->d_tmp, tmp, ka, kb, g->d_idx_a, g->d_idx_b, n, first_bit, key_bits, st));
       }

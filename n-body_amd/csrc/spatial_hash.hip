@@ -39,6 +39,7 @@
 
 #include "common.h"
 #include "onesweep.h"
+#include "radix_sort.h"
 
 // Binning = ONE stable sort by cell id that carries the bodies along: the values are (float4 body, original
 // index) pairs -- a zip of the packed bodies with a counting iterator on the way in, of the cell-ordered body array
@@ -1533,27 +1534,51 @@ __global__ void bbox_decode_rearm_kernel(unsigned int* __restrict__ enc, float* 
 using namespace nbh;
 
 // stable radix sort of the cell ids carrying (body, original index) along; temp == nullptr: size query
+// Which sort bins the bodies (above the crossover size; below it rocPRIM's public sort = a merge sort there):
+//   kSortDriver  rocPRIM's Onesweep device functions under the driver of onesweep.h (fenced: version + self-test) -- the
+//                default while the fence holds: 172 us for the two passes of config 5;
+//   kSortOwn     the hand-written sort of radix_sort.h (no rocPRIM): 207 us -- what runs when the fence does not hold, or
+//                with NBH_SORT=own;
+//   kSortPublic  rocprim::radix_sort_pairs (public API): NBH_SORT=public, and every size below the crossover.
+enum SortImpl { kSortPublic = 0, kSortDriver = 1, kSortOwn = 2 };
+static SortImpl sort_impl_from_env() {
+  const char* e = std::getenv("NBH_SORT");
+  if (e && std::strcmp(e, "own") == 0) return kSortOwn;
+  if (e && std::strcmp(e, "public") == 0) return kSortPublic;
+  if (e && std::strcmp(e, "driver") == 0 && NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE) return kSortDriver;
+  return (NBH_HASH_OWN_SORT && nbh::onesweep::usable()) ? kSortDriver : kSortOwn;
+}
+
+// stable radix sort of the cell ids carrying (body, original index) along; temp == nullptr: size query (room for every path)
 static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned int* keys_in, unsigned int* keys_out,
                                       const float4* bodies_in, float4* bodies_out, int* idx_out, size_t n, int bits,
-                                      hipStream_t st, size_t own_from = nbh::kOwnSortFromGrid, bool cleared = false,
-                                      unsigned int* hist = nullptr) {
+                                      hipStream_t st, SortImpl impl = kSortPublic, bool cleared = false,
+                                      unsigned int* hist = nullptr, unsigned int* error_host = nullptr) {
   auto vin = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_in, rocprim::make_counting_iterator<int>(0)));
   auto vout = rocprim::make_zip_iterator(rocprim::make_tuple(bodies_out, idx_out));
-#if NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE
-  // above rocPRIM's merge-sort range: its Onesweep kernels under our own driver (one fill instead of five, onesweep.h)
-  if (!temp) {  // size query: room for either path
-    size_t a = 0, b = 0;
+  if (!temp) {
+    size_t a = 0, b = 0, c = 0;
     hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, a, keys_in, keys_out, vin, vout, n, 0, bits, st);
     if (e != hipSuccess) return e;
+#if NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE
     e = nbh::onesweep::sort_pairs<NBH_HASH_RADIX_BITS>(nullptr, b, static_cast<const unsigned int*>(keys_in), keys_out, vin, vout,
                                                        n, 0u, (unsigned)bits, st);
-    temp_bytes = a > b ? a : b;
+    if (e != hipSuccess) return e;
+#endif
+    e = nbh::radix::sort_pairs<unsigned int, true>(nullptr, c, static_cast<const unsigned int*>(keys_in), keys_out, bodies_in,
+                                                   bodies_out, nullptr, idx_out, n, 0u, (unsigned)bits, st, nullptr);
+    temp_bytes = std::max(a, std::max(b, c));
     return e;
   }
-  if (n >= own_from)
+#if NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE
+  if (impl == kSortDriver)
     return nbh::onesweep::sort_pairs<NBH_HASH_RADIX_BITS>(temp, temp_bytes, static_cast<const unsigned int*>(keys_in), keys_out,
                                                           vin, vout, n, 0u, (unsigned)bits, st, cleared, hist, nbh::kHistCopies, nbh::kHistWords);
 #endif
+  if (impl == kSortOwn || impl == kSortDriver)  // (a driver request without the driver compiled in: the hand-written sort)
+    return nbh::radix::sort_pairs<unsigned int, true>(temp, temp_bytes, static_cast<const unsigned int*>(keys_in), keys_out,
+                                                      bodies_in, bodies_out, nullptr, idx_out, n, 0u, (unsigned)bits, st, error_host,
+                                                      hist, hist ? nbh::kHistCopies : 1, hist ? (unsigned)nbh::kHistWords : 0u);
   return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vin, vout, n, 0, bits, st);
 }
 
@@ -1561,8 +1586,8 @@ static hipError_t sort_bodies_by_cell(void* temp, size_t& temp_bytes, unsigned i
 // shared by several bodies so that stability shows) through the Onesweep driver and through the public
 // rocprim::radix_sort_pairs; keys, bodies and indices must agree word for word.  Once per process (the first grid).
 static void grid_sort_self_test(hipStream_t st) {
-#if NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE
-  if (nbh::onesweep::self_test_state().load(std::memory_order_acquire) != 0) return;
+  static std::atomic<bool> done{false};
+  if (done.exchange(true)) return;
   const size_t n = 200000;
   const int bits = 20;
   std::vector<unsigned int> hk(n);
@@ -1573,15 +1598,24 @@ static void grid_sort_self_test(hipStream_t st) {
     hk[i] = (x >> 9) & ((1u << bits) - 1u) & ~0x3fu;  // 2^14 distinct cells: ~12 bodies each
     hb[i] = make_float4((float)i, (float)hk[i], 0.f, 1.f);
   }
-  unsigned int *k_in = nullptr, *k_out[2] = {nullptr, nullptr};
-  float4 *b_in = nullptr, *b_out[2] = {nullptr, nullptr};
-  int* i_out[2] = {nullptr, nullptr};
+  constexpr int kV = 3;  // 0: the driver, 1: the public sort, 2: the hand-written sort
+  const SortImpl impl[kV] = {kSortDriver, kSortPublic, kSortOwn};
+  const bool have[kV] = {NBH_HASH_OWN_SORT && NBH_ONESWEEP_AVAILABLE, true, true};
+  unsigned int *k_in = nullptr, *k_out[kV] = {nullptr, nullptr, nullptr};
+  float4 *b_in = nullptr, *b_out[kV] = {nullptr, nullptr, nullptr};
+  int* i_out[kV] = {nullptr, nullptr, nullptr};
+  unsigned int *err_h = nullptr, *err_d = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
-  bool ran = false, same = false;
+  bool ran = false, same[kV] = {false, true, false};
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&k_in), n * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b_in), n * sizeof(float4));
-  for (int v = 0; v < 2 && e == hipSuccess; v++) {
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&err_h), 64, hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *err_h = 0u;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&err_d), err_h, 0);
+  }
+  for (int v = 0; v < kV && e == hipSuccess; v++) {
     e = hipMalloc(reinterpret_cast<void**>(&k_out[v]), n * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b_out[v]), n * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&i_out[v]), n * sizeof(int));
@@ -1590,15 +1624,17 @@ static void grid_sort_self_test(hipStream_t st) {
   if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 16);
   if (e == hipSuccess) e = hipMemcpyAsync(k_in, hk.data(), n * sizeof(unsigned int), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(b_in, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice, st);
-  for (int v = 0; v < 2 && e == hipSuccess; v++) {  // v = 0: the driver (own_from = 0), v = 1: the public sort
+  for (int v = 0; v < kV && e == hipSuccess; v++) {
+    if (!have[v]) continue;
     size_t tb = tmp_bytes;
-    e = sort_bodies_by_cell(tmp, tb, k_in, k_out[v], b_in, b_out[v], i_out[v], n, bits, st, v == 0 ? (size_t)0 : ~(size_t)0);
+    e = sort_bodies_by_cell(tmp, tb, k_in, k_out[v], b_in, b_out[v], i_out[v], n, bits, st, impl[v], false, nullptr, err_d);
   }
   if (e == hipSuccess) {
-    std::vector<unsigned int> rk[2];
-    std::vector<float4> rb[2];
-    std::vector<int> ri[2];
-    for (int v = 0; v < 2 && e == hipSuccess; v++) {
+    std::vector<unsigned int> rk[kV];
+    std::vector<float4> rb[kV];
+    std::vector<int> ri[kV];
+    for (int v = 0; v < kV && e == hipSuccess; v++) {
+      if (!have[v]) continue;
       rk[v].resize(n); rb[v].resize(n); ri[v].resize(n);
       e = hipMemcpyAsync(rk[v].data(), k_out[v], n * sizeof(unsigned int), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipMemcpyAsync(rb[v].data(), b_out[v], n * sizeof(float4), hipMemcpyDeviceToHost, st);
@@ -1607,24 +1643,27 @@ static void grid_sort_self_test(hipStream_t st) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) {
       ran = true;
-      same = std::memcmp(rk[0].data(), rk[1].data(), n * sizeof(unsigned int)) == 0 &&
-             std::memcmp(rb[0].data(), rb[1].data(), n * sizeof(float4)) == 0 &&
-             std::memcmp(ri[0].data(), ri[1].data(), n * sizeof(int)) == 0;
-      for (size_t i = 1; same && i < n; i++) same = rk[0][i - 1] <= rk[0][i];
+      bool sorted = true;
+      for (size_t i = 1; sorted && i < n; i++) sorted = rk[1][i - 1] <= rk[1][i];
+      for (int v = 0; v < kV; v += 2)
+        same[v] = have[v] && sorted && std::memcmp(rk[v].data(), rk[1].data(), n * sizeof(unsigned int)) == 0 &&
+                  std::memcmp(rb[v].data(), rb[1].data(), n * sizeof(float4)) == 0 &&
+                  std::memcmp(ri[v].data(), ri[1].data(), n * sizeof(int)) == 0;
+      if (*err_h) same[2] = false;  // (a look-back of the hand-written sort gave up)
     }
   }
   (void)hipGetLastError();
   (void)hipFree(k_in); (void)hipFree(b_in); (void)hipFree(tmp);
-  for (int v = 0; v < 2; v++) { (void)hipFree(k_out[v]); (void)hipFree(b_out[v]); (void)hipFree(i_out[v]); }
-  nbh::onesweep::self_test_report(ran && same, "spatial-hash (32-bit keys, body + index payload)");
-#else
-  (void)st;
-#endif
+  if (err_h) (void)hipHostFree(err_h);
+  for (int v = 0; v < kV; v++) { (void)hipFree(k_out[v]); (void)hipFree(b_out[v]); (void)hipFree(i_out[v]); }
+  if (have[0]) nbh::onesweep::self_test_report(ran && same[0], "spatial-hash (32-bit keys, body + index payload)");
+  nbh::radix::self_test_report(ran && same[2], "spatial-hash (32-bit keys, body + index payload)");
 }
 
-extern "C" int nbody_hip_sort_info(int* driver_compiled, int* self_test, int* rocprim_version) {
+extern "C" int nbody_hip_sort_info(int* driver_compiled, int* self_test, int* own_self_test, int* rocprim_version) {
   if (driver_compiled) *driver_compiled = NBH_ONESWEEP_AVAILABLE;
   if (self_test) *self_test = nbh::onesweep::self_test_state().load(std::memory_order_acquire);
+  if (own_self_test) *own_self_test = nbh::radix::self_test_state().load(std::memory_order_acquire);
   if (rocprim_version) *rocprim_version = (int)ROCPRIM_VERSION;
   return NBODY_HIP_OK;
 }
@@ -1646,7 +1685,10 @@ struct nbody_hip_grid {
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   unsigned int* d_hist = nullptr;      // digit counts of the sort, accumulated by assign_cells_kernel (kHistWords)
-  size_t own_sort_from = nbh::kOwnSortFromGrid;  // onesweep.h driver from this many bodies
+  size_t own_sort_from = nbh::kOwnSortFromGrid;  // radix sort of our own (driver / hand-written) from this many bodies
+  SortImpl sort_impl = kSortPublic;    // which one (sort_impl_from_env, at creation, after the self-tests)
+  unsigned int* h_sort_err = nullptr;  // mapped host word the hand-written sort raises when a look-back gives up
+  unsigned int* h_sort_err_dev = nullptr;
   int *d_cell_start = nullptr, *d_cell_end = nullptr;  // lazily sized (inspection API only)
   long long cell_capacity = 0;
   int* d_cell_lb = nullptr;            // first sorted position of every cell (+ 1 entry); dense grids only
@@ -1688,6 +1730,7 @@ static void grid_release(nbody_hip_grid* g) {
   (void)hipFree(g->d_cell_end); (void)hipFree(g->d_cell_lb); (void)hipFree(g->d_units); (void)hipFree(g->d_unit_count);
   (void)hipFree(g->d_light);
   if (g->h_unit_hint) (void)hipHostFree(g->h_unit_hint);
+  if (g->h_sort_err) (void)hipHostFree(g->h_sort_err);
   if (g->h_info) (void)hipHostFree(g->h_info);
   delete g;
 }
@@ -1705,7 +1748,15 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
   g->ctx = ctx;
   g->max_particles = max_particles;
   g->own_sort_from = nbh::own_sort_from(nbh::kOwnSortFromGrid);
-  grid_sort_self_test(ctx->stream);  // (once per process: the Onesweep driver against the public sort, onesweep.h)
+  grid_sort_self_test(ctx->stream);  // (once per process: the driver and the hand-written sort against the public sort)
+  g->sort_impl = sort_impl_from_env();
+  if (hipHostMalloc(reinterpret_cast<void**>(&g->h_sort_err), 64, hipHostMallocMapped) == hipSuccess) {
+    *g->h_sort_err = 0u;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->h_sort_err_dev), g->h_sort_err, 0) != hipSuccess) g->h_sort_err_dev = nullptr;
+  } else {
+    g->h_sort_err = nullptr;
+  }
+  (void)hipGetLastError();
   g->cell_size = cell_size;
   const size_t n = max_particles;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_enc), 8 * sizeof(unsigned int));
@@ -1853,9 +1904,17 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   }
   const int sort_bits = bits_for(g->info.total);
-  const bool own_sort = NBH_HASH_OWN_SORT && nbh::onesweep::usable() && n >= g->own_sort_from;
-  const size_t zero_words = own_sort ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)sort_bits) : 0;
-  const int hist_places = own_sort && sort_bits <= kHistPlaces * NBH_HASH_RADIX_BITS
+  // which sort (SortImpl): above the crossover the driver of rocPRIM's Onesweep kernels while its fence holds, else the
+  // hand-written sort; below it (and with NBH_SORT=public) the public rocPRIM sort.  Both of the first two take the digit
+  // counts from assign_cells_kernel; only the driver also wants its look-back block cleared there.
+  if (g->h_sort_err && *g->h_sort_err)
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "the radix sort of an earlier build gave up in its look-back (csrc/radix_sort.h)");
+  SortImpl impl = n >= g->own_sort_from ? g->sort_impl : kSortPublic;
+  if (impl == kSortDriver && !(NBH_HASH_OWN_SORT && nbh::onesweep::usable())) impl = kSortOwn;
+  if (impl == kSortOwn && (!nbh::radix::usable() || !g->h_sort_err_dev)) impl = kSortPublic;
+  const bool driver = impl == kSortDriver;
+  const size_t zero_words = driver ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)sort_bits) : 0;
+  const int hist_places = impl != kSortPublic && sort_bits <= kHistPlaces * NBH_HASH_RADIX_BITS
                               ? (sort_bits + NBH_HASH_RADIX_BITS - 1) / NBH_HASH_RADIX_BITS : 0;
   hipLaunchKernelGGL(assign_cells_kernel, dim3(std::min((ni + kHistThreads - 1) / kHistThreads, NBH_HIST_BLOCKS)), dim3(kHistThreads), 0, st, posm, ni, g->d_info,
                      g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words,
@@ -1864,8 +1923,7 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   size_t tmp = g->sort_tmp_bytes;
   // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
   NBH_HIP(sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n,
-                              sort_bits, st, own_sort ? (size_t)0 : ~(size_t)0, /*cleared=*/own_sort,
-                              hist_places ? g->d_hist : nullptr));
+                              sort_bits, st, impl, /*cleared=*/driver, hist_places ? g->d_hist : nullptr, g->h_sort_err_dev));
   g->lb_valid = false;
   {
     // cells the per-cell start array covers: the whole grid, or the z layers of this rank's slab
