@@ -678,6 +678,47 @@ struct CellTargets<GUARD, 1> {
   __device__ __forceinline__ float get(int, int c) const { return c == 0 ? ax : (c == 1 ? ay : az); }
 };
 
+// The box of a wave's targets: minimum / maximum over the 64 lanes of three coordinates each, without LDS.  Four row
+// shifts (the running extremum of a row of 16 ends up in its last lane), then gfx9's two row broadcasts (lane 15 of a row
+// into the next row, lane 31 into the upper half): six DPP instructions per value, the result in lane 63, returned
+// wave-uniform (SGPRs).  Written out in assembly: through __builtin_amdgcn_update_dpp + fminf the compiler produced a
+// v_mov_b32_dpp, a copy and up to three canonicalising v_max_f32 per step (150 instructions, as many as two LDS
+// shuffles per step cost); here the six chains are interleaved, which also puts the five independent instructions between
+// a write and the DPP read of the same register that the hardware wants (two wait states; s_nop in front for the first).
+// A lane without a source in its row (bound_ctrl off) is not written and keeps its value.
+#ifndef NBH_HASH_DPP_BOX
+#define NBH_HASH_DPP_BOX 1
+#endif
+#ifndef NBH_HASH_PREFETCH_FIX
+#define NBH_HASH_PREFETCH_FIX 1
+#endif
+#ifndef NBH_HASH_PAR_REDUCE
+#define NBH_HASH_PAR_REDUCE 1
+#endif
+__device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3]) {
+#define NBH_BOX_STEP(ctrl)                       \
+  "v_min_f32_dpp %0, %0, %0 " ctrl "\n\t"        \
+  "v_min_f32_dpp %1, %1, %1 " ctrl "\n\t"        \
+  "v_min_f32_dpp %2, %2, %2 " ctrl "\n\t"        \
+  "v_max_f32_dpp %3, %3, %3 " ctrl "\n\t"        \
+  "v_max_f32_dpp %4, %4, %4 " ctrl "\n\t"        \
+  "v_max_f32_dpp %5, %5, %5 " ctrl "\n\t"
+  asm("s_nop 1\n\t"
+      NBH_BOX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+      NBH_BOX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+      NBH_BOX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+      NBH_BOX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+      NBH_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      NBH_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+#undef NBH_BOX_STEP
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo[a]), 63));
+    hi[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi[a]), 63));
+  }
+}
+
 // KC consecutive cells per wave, software-pipelined: while the wave evaluates cell c out of LDS, the
 // loads of cell c+1's window are already in flight (into registers), so that only the first of a
 // wave's cells pays the global-memory latency of its lookups.
@@ -818,15 +859,34 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
 #define NBH_PRE(c, r) __builtin_amdgcn_readlane(vpre, 16 * (c) + (r))
 
   float4 pf[9];  // first 64 entries of each run of the NEXT cell to be evaluated
+  // (the explicit wait and the lane reads in front of the branches: the compiler's wait-count pass merges "maybe pending"
+  // at every join, and with the lookup registers first read inside the conditional blocks it put s_waitcnt vmcnt(0) in
+  // front of every one of the nine loads -- nine round trips to memory one after the other, per cell)
+#if NBH_HASH_PREFETCH_FIX
+#define NBH_PREFETCH(c)                                                                              \
+  __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): nothing useful is in flight here */              \
+  _Pragma("unroll") for (int r = 0; r < 9; r++) {                                                    \
+    const int p0 = NBH_PRE(c, r), b = FILTER ? NBH_PRE(c, r + 1) : min(NBH_PRE(c, r + 1), kWinCap);  \
+    const int sg = NBH_SEG0(c, r);                                                                   \
+    pf[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+    if (p0 < b) pf[r] = sorted[sg + (min(p0 + lane, b - 1) - p0)];                                   \
+  }
+#else
 #define NBH_PREFETCH(c)                                                                              \
   _Pragma("unroll") for (int r = 0; r < 9; r++) {                                                    \
     const int p0 = NBH_PRE(c, r), b = FILTER ? NBH_PRE(c, r + 1) : min(NBH_PRE(c, r + 1), kWinCap);  \
     pf[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
     if (p0 < b) pf[r] = sorted[NBH_SEG0(c, r) + (min(p0 + lane, b - 1) - p0)];                       \
   }
+#endif
   NBH_PREFETCH(0)
 
-#pragma unroll
+  // (the filtered form is not unrolled over the wave's cells: 46 KB of code ran 10 % slower than 24 KB -- instruction
+  // fetch; the plain form is small enough: 30 KB unrolled and 2 % faster than rolled)
+#ifndef NBH_HASH_CELL_UNROLL
+#define NBH_HASH_CELL_UNROLL FILTER ? 1 : KC
+#endif
+#pragma unroll NBH_HASH_CELL_UNROLL
   for (int c = 0; c < KC; c++) {
     int t0 = NBH_SEG0(c, 9), t1 = NBH_SEG0(c, 10);
     if constexpr (UNITS) {  // one chunk of the cell's bodies
@@ -860,6 +920,9 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
         }
       }
       if constexpr (FILTER) {  // the box of the chunk's targets (every lane holds valid targets)
+#if NBH_HASH_DPP_BOX
+        wave_box(blo, bhi);
+#else
 #pragma unroll
         for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -868,6 +931,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
             bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], off, 64));
           }
         }
+#endif
       }
       if constexpr (FILTER) {
       // the pair loop over the Lb entries LDS holds
@@ -915,27 +979,37 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       const float keep2 = cutoff2 * 1.00001f;
       int wcount = 0;
       __builtin_amdgcn_wave_barrier();
+      auto put = [&](const float4 e, const bool have) {  // one round: the box test and the compacting store
+        const float ex = fmaxf(fmaxf(blo[0] - e.x, e.x - bhi[0]), 0.f);
+        const float ey = fmaxf(fmaxf(blo[1] - e.y, e.y - bhi[1]), 0.f);
+        const float ez = fmaxf(fmaxf(blo[2] - e.z, e.z - bhi[2]), 0.f);
+        // (a NaN distance -- non-finite positions -- keeps the entry: its pairs take the ordinary path)
+        const bool keep = have && !(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > keep2);
+        const unsigned long long mask = __ballot(keep);
+        if (keep)
+          win[wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = e;
+        wcount += __builtin_amdgcn_readfirstlane(__popcll(mask));
+      };
+      if (Lw <= kWinCap && prefetched) {
+        // the whole window fits (every cell but the crowded ones) and its first 64 entries per run are in registers: nine
+        // straight-line rounds and ONE pair loop behind them
 #pragma unroll
-      for (int r = 0; r < 9; r++) {
-        const int len = NBH_PRE(c, r + 1) - NBH_PRE(c, r), seg = NBH_SEG0(c, r);
-        for (int v = 0; v < len; v += 64) {
-          if (wcount + 64 > kWinCap) {
-            evaluate(wcount);
-            wcount = 0;
+        for (int r = 0; r < 9; r++) {
+          const int len = NBH_PRE(c, r + 1) - NBH_PRE(c, r), seg = NBH_SEG0(c, r);
+          if (len > 0) put(pf[r], lane < len);
+          for (int v = 64; v < len; v += 64) put(sorted[seg + min(v + lane, len - 1)], v + lane < len);
+        }
+      } else {
+#pragma unroll 1
+        for (int r = 0; r < 9; r++) {
+          const int len = NBH_PRE(c, r + 1) - NBH_PRE(c, r), seg = NBH_SEG0(c, r);
+          for (int v = 0; v < len; v += 64) {
+            if (wcount + 64 > kWinCap) {
+              evaluate(wcount);
+              wcount = 0;
+            }
+            put(sorted[seg + min(v + lane, len - 1)], v + lane < len);
           }
-          const bool have = v + lane < len;
-          float4 e;
-          if (v == 0 && prefetched) e = pf[r];
-          else e = sorted[seg + min(v + lane, len - 1)];
-          const float ex = fmaxf(fmaxf(blo[0] - e.x, e.x - bhi[0]), 0.f);
-          const float ey = fmaxf(fmaxf(blo[1] - e.y, e.y - bhi[1]), 0.f);
-          const float ez = fmaxf(fmaxf(blo[2] - e.z, e.z - bhi[2]), 0.f);
-          // (a NaN distance -- non-finite positions -- keeps the entry: its pairs take the ordinary path)
-          const bool keep = have && !(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > keep2);
-          const unsigned long long mask = __ballot(keep);
-          if (keep)
-            win[wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = e;
-          wcount += __builtin_amdgcn_readfirstlane(__popcll(mask));
         }
       }
       if (prefetched) {
@@ -1016,6 +1090,31 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if NBH_HASH_PAR_REDUCE
+      // lane (component, slot) of the first 3 T: the S slice sums of one component of the slot's R targets, in slice
+      // order as before (the same fp64 additions: bit-identical), on three times as many lanes
+      for (int j = lane; j < 3 * T; j += 64) {
+        const int comp = (j * magic) >> 16, sl2 = j - comp * T;  // j / T, j % T (T <= 32: j < 96)
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          const int t = tb + sl2 + q * T;
+          if (t < tb + cnt) {
+            const double* rp = red + (q * 3 + comp) * 64 + sl2;
+            double f = 0.0;
+            for (int s2 = 0; s2 < S; s2++, rp += T) f += *rp;
+            const int i = idx[t];
+            const float o = (float)((double)G * f);
+            if (acc4) {
+              float* a = reinterpret_cast<float*>(acc4 + i);
+              a[comp] = accumulate ? a[comp] + o : o;
+              if (comp == 0) a[3] = 0.f;
+            } else {
+              (comp == 0 ? acc_x : (comp == 1 ? acc_y : acc_z))[i] = o;
+            }
+          }
+        }
+      }
+#else
       if (lane < T) {
 #pragma unroll
         for (int q = 0; q < R; q++) {
@@ -1042,6 +1141,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
           }
         }
       }
+#endif
     }
     if (prefetched && c + 1 < KC) {  // an empty cell (or an empty window): pass the pipeline on
       __builtin_amdgcn_wave_barrier();
