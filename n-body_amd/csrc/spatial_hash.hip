@@ -645,9 +645,14 @@ struct CellTargets {
         f.x = ok0 ? f.x : 0.f;
         f.y = ok1 ? f.y : 0.f;
       } else {
-        f2 t;  // 1 where d2 < cutoff^2 (:131, unsoftened distance), else 0
-        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(d2), "v"(nbig), "v"(kk));
-        f = (inv * (t * (f2)(s.w))) * (inv * inv);
+        // t = 1 where d2 < cutoff^2 (:131, unsoftened distance), else 0; tm = t m, the mass taken from the upper half of
+        // the entry's (z, w) register pair by operand selection (the compiler copied w into a register of its own first);
+        // -1 / h comes from its scalar register pair (one scalar operand per instruction is allowed)
+        f2 t, tm;
+        const f2 zw = {s.z, s.w};
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(d2), "s"(nbig), "v"(kk));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(tm) : "v"(t), "v"(zw));
+        f = (inv * tm) * (inv * inv);
       }
       ax[j] = __builtin_elementwise_fma(f, dx, ax[j]);
       ay[j] = __builtin_elementwise_fma(f, dy, ay[j]);
@@ -692,6 +697,9 @@ struct CellTargets<GUARD, 1> {
 #ifndef NBH_HASH_PREFETCH_FIX
 #define NBH_HASH_PREFETCH_FIX 1
 #endif
+#ifndef NBH_HASH_PAD_TAIL
+#define NBH_HASH_PAD_TAIL 1
+#endif
 #ifndef NBH_HASH_PAR_REDUCE
 #define NBH_HASH_PAR_REDUCE 1
 #endif
@@ -724,12 +732,14 @@ __device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3]) {
 // wave's cells pays the global-memory latency of its lookups.
 constexpr int kCellsPerWave = 4;
 constexpr double kFilterFrom = 40.0;  // bodies per cell from which the filtered form pays when cutoff > cell (see FILTER below)
-constexpr double kBodyBelow = 10.0;   // bodies per cell below which one lane takes one body (hash_body_force_kernel)
+constexpr double kBodyBelow = 8.0;    // bodies per cell below which one lane takes one body (hash_body_force_kernel): 0.72 against
+                                      // 0.96 ms at 6.6 per cell, 0.85 against 0.81 at 8.8 (profiles/r04_hash_kernels.txt)
 constexpr int kSplitFrom = 500000;   // bodies from which the automatic form below kBodyBelow is the split one
 constexpr int kSplitCnt = NBH_HASH_SPLIT_CNT;  // ... except the bodies of cells this crowded: wave per cell (split form)
-constexpr double kFilterFromInside = 13.0;  // ... and when cutoff <= cell: with the compare-free decision (round 4) the box test
-                                           // pays from ~13 per cell (0.96 against 0.99 ms at 15 per cell, 0.98 against 0.91 ms
-                                           // at 11, 0.67 against 0.97 ms at cutoff = cell / 2: profiles/r04_hash_kernels.txt)
+constexpr double kFilterFromInside = 8.0;  // ... and when cutoff <= cell: everywhere the wave-per-cell form runs at all (with the
+                                          // straight-line gather of round 4 the box test pays from ~8 per cell: 0.81 against
+                                          // 0.84 ms at 8.8 per cell, 0.78 against 0.86 at 11.2, 0.68 against 0.78 at 14.6,
+                                          // 0.52 against 0.93 at cutoff = cell / 2: profiles/r04_hash_kernels.txt)
 
 // A grid as the force kernel sees it.  lb covers the cells [base, base + count] of the (global) grid --
 // the whole grid, or the z-slab a rank holds (sharded path); cells outside hold no bodies of this grid.
@@ -768,15 +778,23 @@ struct CellGridView {
 // own.  Exact: what is kept is evaluated as before (in window order), what is dropped would have contributed 0; the
 // margin of 1e-5 covers the rounding of the two distance computations.  Not bit-identical to the unfiltered form: the
 // kept entries fall to other slices, so the partial sums group differently.
+// Waves per workgroup.  The waves of a workgroup share nothing (every wave has its own LDS region and its own cells); what
+// the workgroup size decides is when the LDS and the wave slots come back: a workgroup's resources are released when its
+// LAST wave ends, and the waves of one workgroup take very different times (four cells each, 5 to 25 bodies).
+#ifndef NBH_HASH_CELL_WPB
+#define NBH_HASH_CELL_WPB 1
+#endif
+constexpr int kCellWPB = NBH_HASH_CELL_WPB;
+static_assert(kCellWPB == 1 || kCellWPB == 2 || kCellWPB == 4, "the launch geometry is counted in groups of four waves");
 template <bool GUARD, int R, bool HALF = false, bool UNITS = false, bool FILTER = false>
-__global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
+__global__ __launch_bounds__(64 * kCellWPB) void hash_cell_force_kernel(
     const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
     float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
     const int2* __restrict__ units = nullptr, const int* __restrict__ unit_count = nullptr,
     int* __restrict__ unit_count_host = nullptr, int unit_capacity = 0, int crowded_only = 0) {
   constexpr int KC = kCellsPerWave;
-  __shared__ float4 win_all[4][kWinCap];
+  __shared__ float4 win_all[kCellWPB][kWinCap + 64];  // (+ 64: the padding of the filtered form's last round)
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   float4* win = win_all[w];
@@ -787,8 +805,9 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
   const int* __restrict__ idx = tgv.idx;
   // workgroup b runs on XCD b mod 8: give every XCD one contiguous eighth of the cells (z slabs), so
   // that neighbouring cells, whose windows overlap, share an L2
-  const long long blk = (long long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
-  const long long cell0 = cell_first + (blk * 4 + w) * KC;
+  // (blocks_per_xcd counts groups of four waves whatever the workgroup size)
+  const long long wid = (long long)(blockIdx.x & 7) * (blocks_per_xcd * 4) + (long long)(blockIdx.x >> 3) * kCellWPB + w;
+  const long long cell0 = cell_first + wid * KC;
   int grp = 0, grp_end = 0, n_units = 0, n_heavy = 0;  // UNITS: this wave's next group of KC units, the end of the list
   if constexpr (UNITS) {
     n_heavy = __builtin_amdgcn_readfirstlane(unit_count[0]);
@@ -800,7 +819,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     // split form (launch_cell_forces kern 9): without a crowded cell the one-lane-per-body kernel has taken every body
     if (crowded_only && __builtin_amdgcn_readfirstlane(unit_count[1]) == 0) return;
     // the list front to back in workgroup order (heavy units first, see cell_units_kernel)
-    grp = (int)blockIdx.x * 4 + w;
+    grp = (int)blockIdx.x * kCellWPB + w;
     grp_end = (n_units + KC - 1) / KC;
   } else {
     if (cell0 >= cell_end) return;
@@ -859,6 +878,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
 #define NBH_PRE(c, r) __builtin_amdgcn_readlane(vpre, 16 * (c) + (r))
 
   float4 pf[9];  // first 64 entries of each run of the NEXT cell to be evaluated
+  const unsigned lane16 = (unsigned)lane << 4;
   // (the explicit wait and the lane reads in front of the branches: the compiler's wait-count pass merges "maybe pending"
   // at every join, and with the lookup registers first read inside the conditional blocks it put s_waitcnt vmcnt(0) in
   // front of every one of the nine loads -- nine round trips to memory one after the other, per cell)
@@ -869,7 +889,9 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
     const int p0 = NBH_PRE(c, r), b = FILTER ? NBH_PRE(c, r + 1) : min(NBH_PRE(c, r + 1), kWinCap);  \
     const int sg = NBH_SEG0(c, r);                                                                   \
     pf[r] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
-    if (p0 < b) pf[r] = sorted[sg + (min(p0 + lane, b - 1) - p0)];                                   \
+    if (p0 < b) /* uniform base + one clamped 32-bit byte offset: one VALU instruction per load */    \
+      pf[r] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sorted + sg) +          \
+                                               (size_t)min(lane16, (unsigned)(b - 1 - p0) << 4));    \
   }
 #else
 #define NBH_PREFETCH(c)                                                                              \
@@ -936,13 +958,22 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
       if constexpr (FILTER) {
       // the pair loop over the Lb entries LDS holds
       auto evaluate = [&](int Lb) {
+        const int iters = (Lb + S - 1) / S;
+#if NBH_HASH_PAD_TAIL
+        // entries of mass 0 up to iters S: every slice then holds exactly iters entries and the loop needs neither a
+        // remainder nor a validity test (a padding entry contributes (inv (t 0)) (inv inv) = +0: eps^2 > 0 here, and the
+        // GUARD form selects its 0); the region has room for kWinCap + 64
+        if (lane < iters * S - Lb) win[Lb + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int iters = (Lb + S - 1) / S;
         const float4* wp = win + (live ? sl : 0);
-        for (int i0 = 0; i0 < iters - 1; i0 += 32) {
-          const int i1 = min(i0 + 32, iters - 1);
+        const int full = NBH_HASH_PAD_TAIL ? iters : iters - 1;
+        // (fp32 partial sums of at most 64 entries -- what the a-priori bound of DESIGN.md section 4.4 is derived for, and
+        // what the lane-per-body kernel does; the unfiltered form below folds every 32)
+        for (int i0 = 0; i0 < full; i0 += 64) {
+          const int i1 = min(i0 + 64, full);
           tg.clear();
           if constexpr (R == 1 || GUARD) {
 #pragma unroll 4
@@ -962,6 +993,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
 #pragma unroll
           for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
         }
+#if !NBH_HASH_PAD_TAIL
         {  // the lane's last entry may lie past the batch
           const bool valid = (int)(wp - win) < Lb;
           float4 s = win[valid ? (int)(wp - win) : 0];
@@ -971,6 +1003,7 @@ __global__ __launch_bounds__(kBlock) void hash_cell_force_kernel(
 #pragma unroll
           for (int q = 0; q < R; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
         }
+#endif
         __builtin_amdgcn_wave_barrier();
       };
       // the window into LDS, run by run, 64 entries at a time, the entries out of reach left out (stable: the kept ones
@@ -2321,11 +2354,11 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
     if (ublocks < 8) ublocks = 8;
     const int uper = (int)((ublocks + 7) / 8);
     if (guard)
-      hipLaunchKernelGGL((hash_cell_force_kernel<true, 2, false, true, NBH_HASH_SPLIT_FILTER>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((hash_cell_force_kernel<true, 2, false, true, NBH_HASH_SPLIT_FILTER>), dim3((unsigned)(uper * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0, ctx->stream,
                          tv, sv, gx, gy, gz, cell_first, cell_end, uper, cutoff2, eps2, G, ax, ay, az, acc4, accumulate,
                          gt->d_units, cur, uhint, (int)gt->units_cap, 1);
     else
-      hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, false, true, NBH_HASH_SPLIT_FILTER>), dim3((unsigned)(uper * 8)), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, false, true, NBH_HASH_SPLIT_FILTER>), dim3((unsigned)(uper * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0, ctx->stream,
                          tv, sv, gx, gy, gz, cell_first, cell_end, uper, cutoff2, eps2, G, ax, ay, az, acc4, accumulate,
                          gt->d_units, cur, uhint, (int)gt->units_cap, 1);
     NBH_LAUNCH_CHECK();
@@ -2374,11 +2407,11 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
 #define NBH_CELL_LAUNCH(GD, RR)                                                                                  \
   do {                                                                                                           \
     if (by_units)                                                                                                \
-      hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR, false, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR, false, true>), dim3((unsigned)(per_xcd * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0, \
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
                          acc4, accumulate, units, ucount, uhint, (int)gt->units_cap);                                                \
     else                                                                                                         \
-      hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0,        \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, RR>), dim3((unsigned)(per_xcd * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0,        \
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
                          acc4, accumulate);                                                                      \
   } while (0)
@@ -2397,7 +2430,7 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
     if (guard) NBH_CELL2_LAUNCH(true); else NBH_CELL2_LAUNCH(false);
 #undef NBH_CELL2_LAUNCH
   } else if (kern == 5) {  // timing probe (see the kernel): not forces
-    hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, ctx->stream, tv,
+    hipLaunchKernelGGL((hash_cell_force_kernel<false, 2, true>), dim3((unsigned)(per_xcd * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0, ctx->stream, tv,
                        sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az, acc4, accumulate);
   } else if (kern == 2) { if (guard) NBH_CELL_LAUNCH(true, 1); else NBH_CELL_LAUNCH(false, 1); }
   else if (kern == 4) { if (guard) NBH_CELL_LAUNCH(true, 4); else NBH_CELL_LAUNCH(false, 4); }
@@ -2405,11 +2438,11 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
 #define NBH_CELL_LAUNCH_F(GD)                                                                                    \
   do {                                                                                                           \
     if (by_units)                                                                                                \
-      hipLaunchKernelGGL((hash_cell_force_kernel<GD, 2, false, true, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, 2, false, true, true>), dim3((unsigned)(per_xcd * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0, \
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
                          acc4, accumulate, units, ucount, uhint, (int)gt->units_cap);                            \
     else                                                                                                         \
-      hipLaunchKernelGGL((hash_cell_force_kernel<GD, 2, false, false, true>), dim3((unsigned)(per_xcd * 8)), dim3(kBlock), 0, \
+      hipLaunchKernelGGL((hash_cell_force_kernel<GD, 2, false, false, true>), dim3((unsigned)(per_xcd * 8 * (4 / kCellWPB))), dim3(64 * kCellWPB), 0, \
                          ctx->stream, tv, sv, gx, gy, gz, cell_first, cell_end, per_xcd, cutoff2, eps2, G, ax, ay, az,   \
                          acc4, accumulate);                                                                      \
   } while (0)
