@@ -377,6 +377,46 @@ __global__ __launch_bounds__(kBlock) void cell_lb_kernel(const unsigned int* __r
   cell_lb[t] = lo;
 }
 
+// The same array from the other side (round 4; grids with at most two cells per body): ONE THREAD PER SORTED POSITION.
+// Position k owns the cells (keys[k - 1], keys[k]] -- their lower bound is k -- and position n the cells behind the last
+// key: most threads find their predecessor in the same cell and leave, the first body of a cell stores one word, a short
+// run of empty cells is filled by that thread, and a long one (64 cells or more: the empty top layers of a grid whose
+// dimensions are ceil(extent / cell) + 1 are thousands) goes to a list that cell_gap_kernel fills with a workgroup per
+// run.  Two coalesced key reads per body instead of ~19 dependent probes per cell (the uniform-density guess above is off
+// by the square root of the position -- up to 2,000 bodies -- so it gallops eight times and then bisects): 8 + 3 us
+// against 28 us at 4.2 M bodies, the same values.  The list's counters alternate between builds: the fill kernel of one
+// build zeroes the counter of the next.
+constexpr int kGapInline = 64;
+__global__ __launch_bounds__(kBlock) void cell_mark_kernel(const unsigned int* __restrict__ keys, int n, int base, int count,
+                                                           int* __restrict__ cell_lb, int* __restrict__ gap_count,
+                                                           int* __restrict__ gaps) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k > n) return;
+  const long long first = base, last = (long long)base + count;                    // the table's cells [first, last]
+  const long long prev = k == 0 ? first - 1 : (long long)keys[k - 1];
+  const long long cur = k == n ? last : (long long)keys[k];
+  if (cur == prev) return;
+  const long long lo = prev + 1 > first ? prev + 1 : first, hi = cur < last ? cur : last;
+  if (lo > hi) return;
+  if (hi - lo < kGapInline) {
+    for (long long c = lo; c <= hi; c++) cell_lb[c - first] = k;
+  } else {
+    const int slot = atomicAdd(gap_count, 1);  // at most (count + 1) / kGapInline + 1 runs this long fit in the table
+    gaps[3 * slot] = (int)(lo - first);
+    gaps[3 * slot + 1] = (int)(hi - first);
+    gaps[3 * slot + 2] = k;
+  }
+}
+__global__ __launch_bounds__(kBlock) void cell_gap_kernel(const int* __restrict__ gap_count, const int* __restrict__ gaps,
+                                                          int* __restrict__ cell_lb, int* __restrict__ next_count) {
+  const int ng = *gap_count;
+  for (int g = blockIdx.x; g < ng; g += gridDim.x) {
+    const int lo = gaps[3 * g], hi = gaps[3 * g + 1], k = gaps[3 * g + 2];
+    for (int c = lo + (int)threadIdx.x; c <= hi; c += kBlock) cell_lb[c] = k;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+}
+
 // The same array for grids with more cells than bodies, where the bodies are anything but evenly spread (a box that
 // has expanded and clumped: 22 M cells for 4.2 M bodies, cells of 400 beside a majority of empty ones) and the
 // uniform-density guess above is off by 10^5 positions: ~30 dependent probes per cell, 0.42 ms.  Two levels instead:
@@ -1844,6 +1884,8 @@ struct nbody_hip_grid {
   int use_units = 1;                   // NBH_HASH_UNITS in the environment at creation: 0 = never (the cell-range form,
                                        // A/B), 2 = always (tests), default 1 = by the statistics of the previous call
   long long lb_capacity = 0;
+  unsigned gap_tick = 0;          // which of the two gap-list counters this build uses (cell_mark_kernel)
+  bool lb_by_position = true;     // NBH_HASH_LB=cell: the per-cell search (cell_lb_kernel) instead
   bool lb_valid = false;
   long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
   int slab_z0 = 0, slab_nz = 0;         // packed builds: z layers this grid holds (nz <= 0: all)
@@ -1930,6 +1972,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
           const double v = std::atof(ff);
           if (v > 0.0) g->filter_from_inside = v;
         }
+        if (const char* lbm = std::getenv("NBH_HASH_LB")) g->lb_by_position = !(lbm[0] == 'c');  // "cell": A/B switch
       }
     }
   }
@@ -2078,9 +2121,14 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       g->d_cell_lb = nullptr;
       g->lb_capacity = 0;
       const long long cap = (count + 1) + (count + 1) / 2;  // grids grow and shrink with the box
-      // (+ the coarse level of the two-level search behind it)
-      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), (size_t)(cap + cap / kLbCoarse + 4) * sizeof(int)));
+      // (+ behind it the coarse level of the two-level search, or the two counters and the list of cell_mark_kernel's
+      // long runs of empty cells: three words each, at most cap / kGapInline + 1 of them)
+      static_assert(kGapInline == kLbCoarse, "one scratch area behind the start array serves both");
+      const size_t extra = (size_t)(3 * (cap / kGapInline + 4) + 8);
+      NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), ((size_t)cap + extra) * sizeof(int)));
       g->lb_capacity = cap;
+      NBH_HIP(hipMemsetAsync(g->d_cell_lb + cap, 0, 2 * sizeof(int), st));  // both counters of the gap list
+      g->gap_tick = 0;
     }
     if (dense && count > 2LL * (long long)n) {  // more cells than bodies: two-level search (see cell_lb_coarse_kernel)
       int* coarse = g->d_cell_lb + g->lb_capacity;
@@ -2089,6 +2137,13 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
                          g->d_keys_b, ni, (int)base, (int)count, coarse);
       hipLaunchKernelGGL(cell_lb_fine_kernel, dim3((unsigned)((count + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, (int)base, (int)count, coarse, g->d_cell_lb);
+    } else if (dense && g->lb_by_position) {
+      int* counters = g->d_cell_lb + g->lb_capacity;  // [2], then the list
+      int* cur = counters + (g->gap_tick & 1), *next = counters + ((g->gap_tick + 1) & 1);
+      g->gap_tick++;
+      hipLaunchKernelGGL(cell_mark_kernel, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                         g->d_keys_b, ni, (int)base, (int)count, g->d_cell_lb, cur, counters + 2);
+      hipLaunchKernelGGL(cell_gap_kernel, dim3(64), dim3(kBlock), 0, st, cur, counters + 2, g->d_cell_lb, next);
     } else if (dense) {
       hipLaunchKernelGGL(cell_lb_kernel, dim3((unsigned)((count + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, ni, (int)base, (int)count, g->d_cell_lb);
