@@ -86,7 +86,8 @@ __global__ void bbox_init_kernel(unsigned int* enc) {
 }
 
 // per-thread min/max -> wave64 shuffle reduce -> LDS across the block's 4 waves -> 6 atomics per block
-__device__ __forceinline__ void block_bbox_commit(float (&lo)[3], float (&hi)[3], float (&red)[4][6],
+template <int WAVES = 4>
+__device__ __forceinline__ void block_bbox_commit(float (&lo)[3], float (&hi)[3], float (&red)[WAVES][6],
                                                   unsigned int* __restrict__ enc) {
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -105,7 +106,7 @@ __device__ __forceinline__ void block_bbox_commit(float (&lo)[3], float (&hi)[3]
   if (threadIdx.x < 6) {
     const int a = threadIdx.x;
     float v = red[0][a];
-    for (int k = 1; k < 4; k++) v = a < 3 ? fminf(v, red[k][a]) : fmaxf(v, red[k][a]);
+    for (int k = 1; k < WAVES; k++) v = a < 3 ? fminf(v, red[k][a]) : fmaxf(v, red[k][a]);
     if (a < 3) atomicMin(&enc[a], float_to_ordered(v));
     else atomicMax(&enc[a], float_to_ordered(v));
   }
@@ -170,7 +171,10 @@ __global__ __launch_bounds__(kBlock) void pack_bbox_kernel(const float* __restri
 
 // the same pass with the drift of the step in front: a_old <- a ; x += v dt + a dt^2/2 (integrator.cu:44-46,
 // :16-19, arithmetic of drift_pack_kernel) ; posm <- {x, y, z, m} ; running min / max of the NEW positions
-__global__ __launch_bounds__(kBlock) void drift_pack_bbox_kernel(float* __restrict__ x, float* __restrict__ y,
+// (BLOCK: the grid stays at <= 256 workgroups for the sake of the six atomics per workgroup -- see bbox_kernel -- so the
+// bytes in flight come from the workgroup size: 1,024 threads = four waves per SIMD instead of one; round 4)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void drift_pack_bbox_kernel(float* __restrict__ x, float* __restrict__ y,
                                                                  float* __restrict__ z, const float* __restrict__ vx,
                                                                  const float* __restrict__ vy, const float* __restrict__ vz,
                                                                  const float* __restrict__ ax, const float* __restrict__ ay,
@@ -178,10 +182,10 @@ __global__ __launch_bounds__(kBlock) void drift_pack_bbox_kernel(float* __restri
                                                                  float* __restrict__ aoy, float* __restrict__ aoz,
                                                                  const float* __restrict__ m, int n, float dt,
                                                                  float4* __restrict__ posm, unsigned int* __restrict__ enc) {
-  __shared__ float red[4][6];
+  __shared__ float red[BLOCK / 64][6];
   const float dt2_half = 0.5f * dt * dt;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
     const float a0 = ax[i], a1 = ay[i], a2 = az[i];
     aox[i] = a0; aoy[i] = a1; aoz[i] = a2;
     const float4 p = make_float4(drift1(x[i], vx[i], a0, dt, dt2_half), drift1(y[i], vy[i], a1, dt, dt2_half),
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void drift_pack_bbox_kernel(float* __restri
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
     lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
-  block_bbox_commit(lo, hi, red, enc);
+  block_bbox_commit<BLOCK / 64>(lo, hi, red, enc);
 }
 
 int launch_drift_pack_bbox(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt, float4* posm, unsigned int* enc,
@@ -200,9 +204,15 @@ int launch_drift_pack_bbox(nbody_hip_ctx* ctx, nbody_particle_data* d, float dt,
   const int n = (int)d->count;
   const int blocks = (n + kBlock - 1) / kBlock;
   if (init) hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, ctx->stream, enc);
-  hipLaunchKernelGGL(drift_pack_bbox_kernel, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream, d->pos_x,
-                     d->pos_y, d->pos_z, d->vel_x, d->vel_y, d->vel_z, d->acc_x, d->acc_y, d->acc_z, d->acc_old_x,
-                     d->acc_old_y, d->acc_old_z, d->mass, n, dt, posm, enc);
+  if (n >= 256 * 1024) {
+    hipLaunchKernelGGL(drift_pack_bbox_kernel<1024>, dim3(256), dim3(1024), 0, ctx->stream, d->pos_x,
+                       d->pos_y, d->pos_z, d->vel_x, d->vel_y, d->vel_z, d->acc_x, d->acc_y, d->acc_z, d->acc_old_x,
+                       d->acc_old_y, d->acc_old_z, d->mass, n, dt, posm, enc);
+  } else {
+    hipLaunchKernelGGL(drift_pack_bbox_kernel<kBlock>, dim3(blocks < 256 ? blocks : 256), dim3(kBlock), 0, ctx->stream, d->pos_x,
+                       d->pos_y, d->pos_z, d->vel_x, d->vel_y, d->vel_z, d->acc_x, d->acc_y, d->acc_z, d->acc_old_x,
+                       d->acc_old_y, d->acc_old_z, d->mass, n, dt, posm, enc);
+  }
   NBH_LAUNCH_CHECK();
   return NBODY_HIP_OK;
 }
@@ -301,6 +311,11 @@ __global__ void grid_info_kernel(unsigned int* __restrict__ enc, float cell, flo
 __global__ void grid_info_set_kernel(GridInfo gi, GridInfo* __restrict__ info, unsigned int* __restrict__ hist) {
   for (int t = threadIdx.x; t < kHistWords * kHistCopies; t += blockDim.x) hist[t] = 0u;
   if (threadIdx.x == 0) *info = gi;
+}
+
+// (mis-speculated key pass, see grid_build_packed: the digit counts start again)
+__global__ void hist_zero_kernel(unsigned int* __restrict__ hist) {
+  for (int t = threadIdx.x; t < kHistWords * kHistCopies; t += blockDim.x) hist[t] = 0u;
 }
 
 __device__ __forceinline__ int cell_coord(float p, float lo, float cell, int dim) {
@@ -1850,6 +1865,9 @@ struct nbody_hip_grid {
   bool enc_armed = false;              // d_enc holds the empty box (left by the previous build's grid_info_kernel)
   GridInfo* d_info = nullptr;
   int info_seq = 0;                    // sequence number of the last grid_info_kernel (polled in h_info->pad)
+  int last_sort_bits = 0;              // key bits of the previous build: the key pass is launched on them before the grid
+                                       // record is back (0: no speculation); spec_mode: NBH_HASH_SPECULATE=0 off, 2 always wrong (test)
+  int spec_mode = 1;
   GridInfo* h_info = nullptr;          // pinned
   GridInfo* h_info_dev = nullptr;      // the device's address of h_info (null: not mapped, copy instead)
   unsigned int *d_keys_a = nullptr, *d_keys_b = nullptr;
@@ -1973,6 +1991,7 @@ extern "C" int nbody_hip_grid_create(nbody_hip_ctx* ctx, size_t max_particles, f
           if (v > 0.0) g->filter_from_inside = v;
         }
         if (const char* lbm = std::getenv("NBH_HASH_LB")) g->lb_by_position = !(lbm[0] == 'c');  // "cell": A/B switch
+        if (const char* sp = std::getenv("NBH_HASH_SPECULATE")) g->spec_mode = std::atoi(sp);  // 0 off, 2 always wrong (tests)
       }
     }
   }
@@ -2026,6 +2045,27 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   NBH_NOT_CAPTURABLE(ctx, "the spatial-hash grid build");
   hipStream_t st = ctx->stream;
   const int ni = (int)n;
+  // which sort (SortImpl): above the crossover the driver of rocPRIM's Onesweep kernels while its fence holds, else the
+  // hand-written sort; below it (and with NBH_SORT=public) the public rocPRIM sort.  Both of the first two take the digit
+  // counts from assign_cells_kernel; only the driver also wants its look-back block cleared there.
+  auto pick_impl = [&]() {
+    SortImpl impl = n >= g->own_sort_from ? g->sort_impl : kSortPublic;
+    if (impl == kSortDriver && !(NBH_HASH_OWN_SORT && nbh::onesweep::usable())) impl = kSortOwn;
+    if (impl == kSortOwn && (!nbh::radix::usable() || !g->h_sort_err_dev)) impl = kSortPublic;
+    return impl;
+  };
+  auto places_for = [&](SortImpl impl, int bits) {
+    return impl != kSortPublic && bits <= kHistPlaces * NBH_HASH_RADIX_BITS ? (bits + NBH_HASH_RADIX_BITS - 1) / NBH_HASH_RADIX_BITS : 0;
+  };
+  // the key pass (assign_cells_kernel) for a grid of `bits` key bits
+  auto key_pass = [&](int bits) {
+    const SortImpl impl = pick_impl();
+    const size_t zero_words = impl == kSortDriver ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)bits) : 0;
+    hipLaunchKernelGGL(assign_cells_kernel, dim3(std::min((ni + kHistThreads - 1) / kHistThreads, NBH_HIST_BLOCKS)), dim3(kHistThreads), 0, st, posm, ni, g->d_info,
+                       g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words,
+                       g->d_hist, places_for(impl, bits));
+  };
+  int spec_bits = 0;  // the bit count the key pass has already been launched on (0: not yet)
   if (bounds) {
     GridInfo gi{};
     long long total = 1;
@@ -2055,6 +2095,16 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
                        g->h_info_dev, g->d_hist, ++g->info_seq);
     NBH_LAUNCH_CHECK();
     g->enc_armed = true;
+    // The key pass does not wait for the host: what it needs of the grid it reads from the device's record, and the two
+    // launch parameters that depend on the grid (how many digit places to count, how many look-back words to clear)
+    // depend on it only through the number of key bits -- which changes when the cell count crosses a power of two.  So
+    // it is launched on the PREVIOUS build's bit count before the record is polled, and runs while the host waits and
+    // prepares the sort; if the count turns out different (or the grid too large), the digit counts are zeroed and the
+    // pass repeated with the right one.  Removes the 9-11 us the GPU idled between grid_info_kernel and the key pass.
+    if (g->spec_mode && g->last_sort_bits > 0) {
+      spec_bits = g->spec_mode == 2 ? (g->last_sort_bits > 10 ? g->last_sort_bits - 10 : g->last_sort_bits + 10) : g->last_sort_bits;
+      key_pass(spec_bits);
+    }
     // the one host round trip of the build: the grid size decides validity (and, for the
     // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
     if (!g->h_info_dev) NBH_HIP(hipMemcpyAsync(g->h_info, g->d_info, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
@@ -2080,22 +2130,19 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   }
   const int sort_bits = bits_for(g->info.total);
-  // which sort (SortImpl): above the crossover the driver of rocPRIM's Onesweep kernels while its fence holds, else the
-  // hand-written sort; below it (and with NBH_SORT=public) the public rocPRIM sort.  Both of the first two take the digit
-  // counts from assign_cells_kernel; only the driver also wants its look-back block cleared there.
   if (g->h_sort_err && *g->h_sort_err)
     return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "the radix sort of an earlier build gave up in its look-back (csrc/radix_sort.h)");
-  SortImpl impl = n >= g->own_sort_from ? g->sort_impl : kSortPublic;
-  if (impl == kSortDriver && !(NBH_HASH_OWN_SORT && nbh::onesweep::usable())) impl = kSortOwn;
-  if (impl == kSortOwn && (!nbh::radix::usable() || !g->h_sort_err_dev)) impl = kSortPublic;
+  if (spec_bits != sort_bits) {
+    if (spec_bits) {
+      hipLaunchKernelGGL(hist_zero_kernel, dim3(1), dim3(256), 0, st, g->d_hist);
+      NBH_LAUNCH_CHECK();
+    }
+    key_pass(sort_bits);
+  }
+  g->last_sort_bits = sort_bits;
+  const SortImpl impl = pick_impl();
   const bool driver = impl == kSortDriver;
-  const size_t zero_words = driver ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)sort_bits) : 0;
-  const int hist_places = impl != kSortPublic && sort_bits <= kHistPlaces * NBH_HASH_RADIX_BITS
-                              ? (sort_bits + NBH_HASH_RADIX_BITS - 1) / NBH_HASH_RADIX_BITS : 0;
-  hipLaunchKernelGGL(assign_cells_kernel, dim3(std::min((ni + kHistThreads - 1) / kHistThreads, NBH_HIST_BLOCKS)), dim3(kHistThreads), 0, st, posm, ni, g->d_info,
-                     g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words,
-                     g->d_hist, hist_places);
-  NBH_LAUNCH_CHECK();
+  const int hist_places = places_for(impl, sort_bits);
   size_t tmp = g->sort_tmp_bytes;
   // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
   NBH_HIP(sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n,

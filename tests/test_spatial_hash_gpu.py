@@ -549,3 +549,33 @@ def test_filtered_form_of_the_cell_kernel(nb, oracle, ctx, monkeypatch, case):
     assert np.all(e <= hash_bound(kappa[nz], "oracle")), (case, e.max())
     if case == "dense":                     # ... where the automatic choice is this form already
         assert np.array_equal(a, auto)
+
+
+# The key pass is launched before the host has the grid record, on the previous build's key-bit count (csrc/spatial_hash.hip
+# grid_build_packed); a box that grows or shrinks across a power of two of cells makes that count wrong and the pass is
+# repeated.  Same grids, same forces with the speculation on, off, and forced wrong at every build; the start array by sorted
+# position (round 4) against the per-cell search in the same breath.
+@pytest.mark.gpu
+def test_key_pass_ahead_of_the_grid_record(nb, ctx, monkeypatch):
+    n = 300000
+    small = nb.ic.uniform_box(n, seed=31, lo=-9.0, hi=9.0)        # 19^3 cells: 13 key bits
+    large = {k: (v * 3.5 if k.startswith("pos") else v) for k, v in small.items()}  # 64^3: 18 key bits
+    got = {}
+    for mode, lb in (("0", "cell"), ("1", "position"), ("2", "position")):
+        monkeypatch.setenv("NBH_HASH_SPECULATE", mode)
+        monkeypatch.setenv("NBH_HASH_LB", lb)
+        grid = nb.SpatialHashGrid(n, 1.0)
+        res = []
+        for ic in (small, small, large, large, small):   # right, wrong (grown), right, wrong (shrunk)
+            d, _ = to_device(nb, ic)
+            grid.build(d)
+            grid.computeForces(d, 1.0, 1.0, 0.05)
+            cs, ce, pc, si = grid.copyCellDataToHost()
+            res.append((cs.copy(), ce.copy(), si.copy(), acc_of(d).copy(), grid.getTotalCells()))
+        got[mode] = res
+    assert got["0"][0][4] < 2 ** 13 < 2 ** 17 < got["0"][2][4]
+    for mode in ("1", "2"):
+        for a, b in zip(got[mode], got["0"]):
+            assert a[4] == b[4]
+            for x, y in zip(a[:4], b[:4]):
+                assert np.array_equal(x, y)
