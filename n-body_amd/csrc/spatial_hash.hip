@@ -987,7 +987,9 @@ __global__ __launch_bounds__(64 * kCellWPB) void hash_cell_force_kernel(
       [[maybe_unused]] float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        const float4 p = tsorted[min(tb + slot + q * T, t1 - 1)];
+        // (uniform base + a clamped 32-bit byte offset: cnt <= 64 R targets, so the offset is below 4 KiB)
+        const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tsorted + tb) +
+                                                          (size_t)((unsigned)min(slot + q * T, t1 - 1 - tb) << 4));
         tg.set(q, p.x, p.y, p.z);
         sx[q] = sy[q] = sz[q] = 0.0;
         if constexpr (FILTER) {
@@ -1179,26 +1181,25 @@ __global__ __launch_bounds__(64 * kCellWPB) void hash_cell_force_kernel(
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if NBH_HASH_PAR_REDUCE
-      // lane (component, slot) of the first 3 T: the S slice sums of one component of the slot's R targets, in slice
-      // order as before (the same fp64 additions: bit-identical), on three times as many lanes
-      for (int j = lane; j < 3 * T; j += 64) {
-        const int comp = (j * magic) >> 16, sl2 = j - comp * T;  // j / T, j % T (T <= 32: j < 96)
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-          const int t = tb + sl2 + q * T;
-          if (t < tb + cnt) {
-            const double* rp = red + (q * 3 + comp) * 64 + sl2;
-            double f = 0.0;
-            for (int s2 = 0; s2 < S; s2++, rp += T) f += *rp;
-            const int i = idx[t];
-            const float o = (float)((double)G * f);
-            if (acc4) {
-              float* a = reinterpret_cast<float*>(acc4 + i);
-              a[comp] = accumulate ? a[comp] + o : o;
-              if (comp == 0) a[3] = 0.f;
-            } else {
-              (comp == 0 ? acc_x : (comp == 1 ? acc_y : acc_z))[i] = o;
-            }
+      // lane (target q, component, slot) of the first 3 R T: the S slice sums of one component of one target, in slice order
+      // as before (the same fp64 additions: bit-identical), on 3 R times as many lanes as one lane per slot -- one pass
+      // for cells of up to 20 bodies
+      for (int j = lane; j < 3 * R * T; j += 64) {
+        const int qc = (j * magic) >> 16, sl2 = j - qc * T;  // j / T, j % T (T <= 32, j < 384: exact)
+        const int q = qc / 3, comp = qc - 3 * q;
+        const int t = tb + sl2 + q * T;
+        if (t < tb + cnt) {
+          const double* rp = red + qc * 64 + sl2;
+          double f = 0.0;
+          for (int s2 = 0; s2 < S; s2++, rp += T) f += *rp;
+          const int i = idx[t];
+          const float o = (float)((double)G * f);
+          if (acc4) {
+            float* a = reinterpret_cast<float*>(acc4 + i);
+            a[comp] = accumulate ? a[comp] + o : o;
+            if (comp == 0) a[3] = 0.f;
+          } else {
+            (comp == 0 ? acc_x : (comp == 1 ? acc_y : acc_z))[i] = o;
           }
         }
       }
