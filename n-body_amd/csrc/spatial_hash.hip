@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void cell_lb_kernel(const unsigned int* __r
 // Position k owns the cells (keys[k - 1], keys[k]] -- their lower bound is k -- and position n the cells behind the last
 // key: most threads find their predecessor in the same cell and leave, the first body of a cell stores one word, a short
 // run of empty cells is filled by that thread, and a long one (64 cells or more: the empty top layers of a grid whose
-// dimensions are ceil(extent / cell) + 1 are thousands) goes to a list that cell_gap_kernel fills with a workgroup per
+// dimensions are ceil(extent / cell) + 1 are thousands) goes to a list that cell_gap_kernel fills with a wave per
 // run.  Two coalesced key reads per body instead of ~19 dependent probes per cell (the uniform-density guess above is off
 // by the square root of the position -- up to 2,000 bodies -- so it gallops eight times and then bisects): 8 + 3 us
 // against 28 us at 4.2 M bodies, the same values.  The list's counters alternate between builds: the fill kernel of one
@@ -425,9 +425,11 @@ __global__ __launch_bounds__(kBlock) void cell_mark_kernel(const unsigned int* _
 __global__ __launch_bounds__(kBlock) void cell_gap_kernel(const int* __restrict__ gap_count, const int* __restrict__ gaps,
                                                           int* __restrict__ cell_lb, int* __restrict__ next_count) {
   const int ng = *gap_count;
-  for (int g = blockIdx.x; g < ng; g += gridDim.x) {
+  // a wave per run (a clumped box has tens of thousands of runs of a few hundred empty cells)
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int g = blockIdx.x * (kBlock / 64) + w; g < ng; g += gridDim.x * (kBlock / 64)) {
     const int lo = gaps[3 * g], hi = gaps[3 * g + 1], k = gaps[3 * g + 2];
-    for (int c = lo + (int)threadIdx.x; c <= hi; c += kBlock) cell_lb[c] = k;
+    for (int c = lo + lane; c <= hi; c += 64) cell_lb[c] = k;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
 }
@@ -2191,7 +2193,7 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       g->gap_tick++;
       hipLaunchKernelGGL(cell_mark_kernel, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, ni, (int)base, (int)count, g->d_cell_lb, cur, counters + 2);
-      hipLaunchKernelGGL(cell_gap_kernel, dim3(64), dim3(kBlock), 0, st, cur, counters + 2, g->d_cell_lb, next);
+      hipLaunchKernelGGL(cell_gap_kernel, dim3(512), dim3(kBlock), 0, st, cur, counters + 2, g->d_cell_lb, next);
     } else if (dense) {
       hipLaunchKernelGGL(cell_lb_kernel, dim3((unsigned)((count + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, ni, (int)base, (int)count, g->d_cell_lb);
