@@ -1096,7 +1096,9 @@ __global__ __launch_bounds__(64 * kCellWPB) void hash_cell_force_kernel(
         for (int r = 0; r < 9; r++) {
           const int len = NBH_PRE(c, r + 1) - NBH_PRE(c, r), seg = NBH_SEG0(c, r);
           for (int v = 0; v < len; v += 64) {
-            if (wcount + 64 > kWinCap) {
+            // (a window of at most kWinCap entries -- a later chunk of a crowded cell in a sparse neighbourhood -- is never
+            // split: the same single batch as the branch above, whichever of the two a form of the kernel takes)
+            if (Lw > kWinCap && wcount + 64 > kWinCap) {
               evaluate(wcount);
               wcount = 0;
             }
