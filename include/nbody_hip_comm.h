@@ -50,6 +50,13 @@
  * layers in one workgroup's LDS): taller grids are refused with NBODY_HIP_ERR_RESOURCE, where the single-GPU grid
  * accepts any shape up to 1e8 cells.  At cell = cutoff that is a box 4,096 cutoffs tall.
  *
+ * Failure of ONE rank in a multi-process run (one process per GPU, nbody_hip_comm_init_rank): the per-step buffers are
+ * sized from the all-reduced send matrix, i.e. after the step's collective decision, and grown with 12-25 % headroom.  A
+ * rank whose hipMalloc fails there returns NBODY_HIP_ERR_RESOURCE while its peers have already entered the point-to-point
+ * group and wait for it: the host must treat a non-OK status of any rank as fatal for the job (destroy the communicator
+ * / end the processes), as bench.py does with its watchdog.  With all ranks in one process (nbody_hip_comm_init_all)
+ * the failing call returns before any rank has posted the group.
+ *
  * Status codes and error text as in nbody_hip.h; RCCL failures are NBODY_HIP_ERR_COMM.
  */
 #ifndef NBODY_HIP_COMM_H
