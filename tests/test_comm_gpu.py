@@ -234,7 +234,7 @@ def _single_gpu_hash_forces(nb, st, mass, G, eps, cell, cutoff):
 @pytest.mark.parametrize("W,n,half,cell,cutoff", [(1, 20000, 6.0, 1.0, 1.0), (2, 30000, 6.0, 1.0, 1.0), (3, 30000, 6.0, 1.0, 2.0),
                                                   (4, 60000, 8.0, 1.0, 1.0), (8, 200000, 12.0, 1.0, 1.0), (4, 3000, 20.0, 1.0, 1.0),
                                                   (8, 5000, 2.0, 1.0, 1.0),
-                                                  # below 10 bodies per cell the two-grid calls take the one-lane-per-body kernel
+                                                  # below 8 bodies per cell the two-grid calls take the one-lane-per-body kernel
                                                   # (layer ranges, accumulate); from 500,000 bodies per rank its split form
                                                   (4, 40000, 9.0, 1.0, 1.0), (2, 1200000, 30.0, 1.0, 1.0)])
 def test_sharded_hash_virtual_ranks_equal_single_gpu(nb, oracle, ctx, W, n, half, cell, cutoff):
