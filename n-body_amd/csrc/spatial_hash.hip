@@ -648,6 +648,9 @@ constexpr int kWinCap = 512;  // window entries a wave holds in LDS at a time (8
 // instructions per window entry in the loop that is 70 % of the kernel.  (A NaN distance gives t = 0 under DX10 clamp:
 // the pair contributes f = 0 as under the compare.)  Needs 1 / h and K representable: cutoff^2 in [2^-100, 2^100];
 // outside, and when eps^2 < 1e-12, the GUARD instantiation (compare + select, d2 > 0 test) runs.
+#ifndef NBH_HASH_PAIR4
+#define NBH_HASH_PAIR4 1
+#endif
 struct CutConst {
   float nbig, k;  // -1 / h, K
 };
@@ -716,6 +719,38 @@ struct CellTargets {
       az[j] = __builtin_elementwise_fma(f, dz, az[j]);
     }
   }
+#if NBH_HASH_PAIR4
+  // four window entries, stage by stage (the four dependent chains side by side: the compiler otherwise runs one entry's
+  // chain after the other and pads the back-to-back dependent packed instructions with s_nop)
+  __device__ __forceinline__ void pair4(const float4 e0, const float4 e1, const float4 e2, const float4 e3, float eps2) {
+    static_assert(NP == 1 && !GUARD, "two targets per lane, compare-free decision");
+    const float4 e[4] = {e0, e1, e2, e3};
+    f2 dx[4], dy[4], dz[4], d2[4], inv[4], t[4], tm[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { dx[k] = (f2)(e[k].x) - px[0]; dy[k] = (f2)(e[k].y) - py[0]; dz[k] = (f2)(e[k].z) - pz[0]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d2[k] = hash_dist2(dx[k], dy[k], dz[k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f2 de = d2[k] + (f2)(eps2);
+      inv[k].x = __builtin_amdgcn_rsqf(de.x);
+      inv[k].y = __builtin_amdgcn_rsqf(de.y);
+      asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t[k]) : "v"(d2[k]), "s"(nbig), "v"(kk));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f2 zw = {e[k].z, e[k].w};
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(tm[k]) : "v"(t[k]), "v"(zw));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f2 f = (inv[k] * tm[k]) * (inv[k] * inv[k]);
+      ax[0] = __builtin_elementwise_fma(f, dx[k], ax[0]);
+      ay[0] = __builtin_elementwise_fma(f, dy[k], ay[0]);
+      az[0] = __builtin_elementwise_fma(f, dz[k], az[0]);
+    }
+  }
+#endif
   __device__ __forceinline__ float get(int q, int c) const {
     return c == 0 ? ax[q >> 1][q & 1] : (c == 1 ? ay[q >> 1][q & 1] : az[q >> 1][q & 1]);
   }
@@ -844,7 +879,7 @@ struct CellGridView {
 constexpr int kCellWPB = NBH_HASH_CELL_WPB;
 static_assert(kCellWPB == 1 || kCellWPB == 2 || kCellWPB == 4, "the launch geometry is counted in groups of four waves");
 template <bool GUARD, int R, bool HALF = false, bool UNITS = false, bool FILTER = false>
-__global__ __launch_bounds__(64 * kCellWPB) void hash_cell_force_kernel(
+__global__ __launch_bounds__(64 * kCellWPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_cell_force_kernel(
     const CellGridView tgv, const CellGridView sgv, int gx, int gy, int gz, long long cell_first,
     long long cell_end, int blocks_per_xcd, float cutoff2, float eps2, float G, float* __restrict__ acc_x,
     float* __restrict__ acc_y, float* __restrict__ acc_z, float4* __restrict__ acc4, int accumulate,
@@ -1042,10 +1077,17 @@ __global__ __launch_bounds__(64 * kCellWPB) void hash_cell_force_kernel(
             int it = i0;
             for (; it + 4 <= i1; it += 4, wp += 4 * S) {
               const float4 e0 = wp[0], e1 = wp[S], e2 = wp[2 * S], e3 = wp[3 * S];
-              tg.pair(e0, cutoff2, eps2);
-              tg.pair(e1, cutoff2, eps2);
-              tg.pair(e2, cutoff2, eps2);
-              tg.pair(e3, cutoff2, eps2);
+#if NBH_HASH_PAIR4
+              if constexpr (R == 2) {
+                tg.pair4(e0, e1, e2, e3, eps2);
+              } else
+#endif
+              {
+                tg.pair(e0, cutoff2, eps2);
+                tg.pair(e1, cutoff2, eps2);
+                tg.pair(e2, cutoff2, eps2);
+                tg.pair(e3, cutoff2, eps2);
+              }
             }
             for (; it < i1; it++, wp += S) tg.pair(*wp, cutoff2, eps2);
           }
