@@ -1117,7 +1117,10 @@ __global__ __launch_bounds__(64 * kCellWPB) __attribute__((amdgpu_waves_per_eu(4
       int wcount = 0;
       __builtin_amdgcn_wave_barrier();
       [[maybe_unused]] const f2 lo_xy = {blo[0], blo[1]}, hi_xy = {bhi[0], bhi[1]};
-      auto put = [&](const float4 e, const bool have) {  // one round: the box test and the compacting store
+      // one round: the box test and the compacting store.  `left` = entries of the run from this round on: the lanes
+      // behind them (which hold a clamped duplicate) are masked out of the ballot on the scalar side -- no per-lane
+      // validity compare, and the store's predicate is the mask itself
+      auto put = [&](const float4 e, const int left) {
 #if NBH_HASH_PK_BOX
         // (x and y side by side in packed subtractions: 10 instead of 13 instructions per round)
         const f2 exy = {e.x, e.y};
@@ -1129,9 +1132,9 @@ __global__ __launch_bounds__(64 * kCellWPB) __attribute__((amdgpu_waves_per_eu(4
 #endif
         const float ez = fmaxf(fmaxf(blo[2] - e.z, e.z - bhi[2]), 0.f);
         // (a NaN distance -- non-finite positions -- keeps the entry: its pairs take the ordinary path)
-        const bool keep = have && !(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > keep2);
-        const unsigned long long mask = __ballot(keep);
-        if (keep)
+        const unsigned long long have_mask = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        const unsigned long long mask = __ballot(!(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > keep2)) & have_mask;
+        if (__builtin_amdgcn_inverse_ballot_w64(mask))
           win[wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = e;
         wcount += __builtin_amdgcn_readfirstlane(__popcll(mask));
       };
@@ -1141,8 +1144,8 @@ __global__ __launch_bounds__(64 * kCellWPB) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int r = 0; r < 9; r++) {
           const int len = NBH_PRE(c, r + 1) - NBH_PRE(c, r), seg = NBH_SEG0(c, r);
-          if (len > 0) put(pf[r], lane < len);
-          for (int v = 64; v < len; v += 64) put(sorted[seg + min(v + lane, len - 1)], v + lane < len);
+          if (len > 0) put(pf[r], len);
+          for (int v = 64; v < len; v += 64) put(sorted[seg + min(v + lane, len - 1)], len - v);
         }
       } else {
 #pragma unroll 1
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(64 * kCellWPB) __attribute__((amdgpu_waves_per_eu(4
               evaluate(wcount);
               wcount = 0;
             }
-            put(sorted[seg + min(v + lane, len - 1)], v + lane < len);
+            put(sorted[seg + min(v + lane, len - 1)], len - v);
           }
         }
       }
