@@ -645,8 +645,9 @@ constexpr int kWinCap = 512;  // window entries a wave holds in LDS at a time (8
 // is exactly 1 for d2 <= c-  <=>  d2 < cutoff^2 (the exact value K - d2 / h is >= 1, and rounding is monotone) and exactly
 // 0 for d2 >= cutoff^2 (exact value <= 0); m t is m or 0 exactly, so the factor (inv (m t)) (inv inv) is bit for bit the
 // selected one.  Two packed instructions instead of two compares and two selects per two pairs: 19 instead of 21
-// instructions per window entry in the loop that is 70 % of the kernel.  (A NaN distance gives t = 0 under DX10 clamp:
-// the pair contributes f = 0 as under the compare.)  Needs 1 / h and K representable: cutoff^2 in [2^-100, 2^100];
+// instructions per window entry in the loop that is 70 % of the kernel.  (A NaN distance -- a non-finite position, which
+// the validators of the interface reject -- gives t = 0 under DX10 clamp but inv = NaN: the pair poisons the target's sum,
+// where the compare form would skip it.  Finite inputs only: an infinite d2 gives inv = 0, t = 0, f = 0.)  Needs 1 / h and K representable: cutoff^2 in [2^-100, 2^100];
 // outside, and when eps^2 < 1e-12, the GUARD instantiation (compare + select, d2 > 0 test) runs.
 #ifndef NBH_HASH_PAIR4
 #define NBH_HASH_PAIR4 1
