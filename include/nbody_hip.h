@@ -234,8 +234,12 @@ NBODY_HIP_API int nbody_hip_grid_set_cell_size(nbody_hip_grid* grid, float cell_
  * run of cells along x, binary-searched ranges; the only one for very sparse grids), 2 / 3 / 4 = wave-per-
  * cell kernel with 1 / 2 / 4 bodies per lane (needs a grid of at most ~4 cells per body).  All give the
  * reference's 27-cell result; they differ by fp rounding of the summation order only.
- * 6 = two bodies per lane with the window filtered by the box of the cell's bodies (automatic from 40 bodies per
- *     occupied cell);
+ * 6 = two bodies per lane with the window filtered by the box of the cell's bodies (automatic from 8 bodies per cell
+ *     when cutoff <= cell_size, from 40 when cutoff > cell_size);
+ * 7 = two-phase form of the wave-per-cell kernel (distance masks first; measured, not the default);
+ * 8 = one lane per body (automatic below 8 bodies per cell), 9 = its split form (8 for the cells of few bodies, 3 for
+ *     the crowded ones: automatic from 500,000 bodies), 10 = two bodies of one cell per lane (measured: 7-17 % faster
+ *     than 8 between 3 and 9 bodies per cell, bound by the L1 path; not chosen automatically);
  * 5 = TIMING PROBE, not a force kernel: the wave-per-cell kernel over the half shell (own cell + 13 forward
  * neighbours) without reactions -- a lower bound for the time of a Newton's-third-law variant;
  * its output is meaningless. */

@@ -517,7 +517,9 @@ class SpatialHashGrid:
 
     def tuning(self, kernel: int = 0):
         """force kernel: 0 automatic, 1 cell-run, 2 / 3 / 4 wave-per-cell with 1 / 2 / 4 bodies per lane, 6 = 3 with the
-        window filtered by the box of the cell's bodies (crowded cells), 5 = timing probe (not forces)"""
+        window filtered by the box of the cell's bodies (crowded cells), 5 = timing probe (not forces), 7 = two-phase form,
+        8 = one lane per body, 9 = split form (8 for the light cells, 3 for the crowded ones), 10 = two bodies of one cell
+        per lane"""
         check(self.ctx._lib.nbody_hip_grid_tuning(self._h, kernel))
 
     def build(self, d_particles: ParticleData):

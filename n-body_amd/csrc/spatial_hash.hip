@@ -1761,6 +1761,93 @@ __global__ __launch_bounds__(kBlock) void hash_body_force_kernel(
 }
 
 // z cell coordinate of every body on a given grid (slab assignment of the sharded path)
+// ---------------------------------------------------------------------------------------
+// TWO BODIES OF ONE CELL PER LANE (round 4, tuning 10).  The lane-per-body kernel above spends 16.75 VALU instructions
+// per candidate pair: it packs two window ENTRIES into the halves of its packed instructions, which costs a register
+// transposition (13 moves per four entries) and a clamped address per entry.  Two TARGETS of the same cell have the same
+// window, so here a lane takes two consecutive bodies of a cell (the list of cell_units_kernel with pair_items: an odd
+// cell's last body alone, its twin a duplicate whose result is dropped) and every entry it loads serves both -- the
+// arithmetic of CellTargets<false, 2>: 17 instructions per entry and TWO targets, half the loads, no transposition.
+// No LDS, no cross-lane step; fp32 partial sums of at most 64 entries folded into fp64 in window order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void hash_body2_force_kernel(
+    const CellGridView tgv, const CellGridView sgv, const unsigned int* __restrict__ tkeys, int gx, int gy, int gz,
+    float cutoff2, float eps2, float G, float* __restrict__ acc_x, float* __restrict__ acc_y, float* __restrict__ acc_z,
+    float4* __restrict__ acc4, int accumulate, const int* __restrict__ items, const int* __restrict__ item_count) {
+  const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+  if (i >= *item_count) return;
+  const int item = items[i];
+  const int t0 = item & 0x7fffffff;
+  const bool single = item < 0;
+  const int t1 = single ? t0 : t0 + 1;
+  const unsigned int c32 = tkeys[t0], layer = (unsigned int)gx * (unsigned int)gy;
+  const float4 p0 = tgv.sorted[t0], p1 = tgv.sorted[t1];
+  const unsigned int uz = c32 / layer, rem = c32 - uz * layer, uy = rem / (unsigned int)gx;
+  const int cx = (int)(rem - uy * (unsigned int)gx), cy = (int)uy, cz = (int)uz;
+  // the nine runs' bounds first: eighteen independent loads in flight, not nine round trips one after the other
+  int k0[9], k1[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+    k0[r] = k1[r] = 0;
+    if (yy >= 0 && yy < gy && zz >= 0 && zz < gz) {
+      const long long base = ((long long)zz * gy + yy) * gx;
+      k0[r] = sgv.lower(base + max(cx - 1, 0));
+      k1[r] = sgv.lower(base + min(cx + 2, gx));
+    }
+  }
+  CellTargets<false, 2> tg;
+  tg.set_cut(cutoff2);
+  tg.set(0, p0.x, p0.y, p0.z);
+  tg.set(1, p1.x, p1.y, p1.z);
+  tg.clear();
+  double sx[2] = {0.0, 0.0}, sy[2] = {0.0, 0.0}, sz[2] = {0.0, 0.0};
+  int run = 0;  // entries in the current fp32 partial sums
+  const char* sb = reinterpret_cast<const char*>(sgv.sorted);
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    for (int kc = k0[r]; kc < k1[r]; kc += 64) {
+      const int kend = min(kc + 64, k1[r]);
+      if (run + (kend - kc) > 64) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
+        tg.clear();
+        run = 0;
+      }
+      run += kend - kc;
+      const int klast = kend - 1;
+      for (int k = kc; k < kend; k += 4) {
+        const float4 e0 = *reinterpret_cast<const float4*>(sb + ((unsigned)k << 4));
+        float4 e1 = *reinterpret_cast<const float4*>(sb + ((unsigned)min(k + 1, klast) << 4));
+        float4 e2 = *reinterpret_cast<const float4*>(sb + ((unsigned)min(k + 2, klast) << 4));
+        float4 e3 = *reinterpret_cast<const float4*>(sb + ((unsigned)min(k + 3, klast) << 4));
+        if (k + 1 > klast) e1.w = 0.f;  // (past the end of the run: its last entry again, with mass 0)
+        if (k + 2 > klast) e2.w = 0.f;
+        if (k + 3 > klast) e3.w = 0.f;
+        tg.pair4(e0, e1, e2, e3, eps2);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) { sx[q] += (double)tg.get(q, 0); sy[q] += (double)tg.get(q, 1); sz[q] += (double)tg.get(q, 2); }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (q == 1 && single) break;
+    const int o = tgv.idx[q ? t1 : t0];
+    const float ox = (float)((double)G * sx[q]), oy = (float)((double)G * sy[q]), oz = (float)((double)G * sz[q]);
+    if (acc4) {
+      if (accumulate) {
+        const float4 a = acc4[o];
+        acc4[o] = make_float4(a.x + ox, a.y + oy, a.z + oz, 0.f);
+      } else {
+        acc4[o] = make_float4(ox, oy, oz, 0.f);
+      }
+    } else {
+      acc_x[o] = ox; acc_y[o] = oy; acc_z[o] = oz;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void cell_z_kernel(const float4* __restrict__ posm, int n,
                                                         float lo_z, float cell, int gz,
                                                         int* __restrict__ cz) {
@@ -2084,7 +2171,7 @@ extern "C" int nbody_hip_grid_set_cell_size(nbody_hip_grid* g, float cell_size) 
 }
 extern "C" int nbody_hip_grid_tuning(nbody_hip_grid* g, int kernel) {
   if (!g) return NBH_FAIL(NBODY_HIP_ERR_STATE, "null grid");
-  if (kernel < 0 || kernel > 9) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..9");
+  if (kernel < 0 || kernel > 10) return NBH_FAIL(NBODY_HIP_ERR_VALIDATION, "kernel must be 0..10");
   g->tune_kernel = kernel;
   return NBODY_HIP_OK;
 }
@@ -2340,7 +2427,7 @@ template <bool BODIES>
 __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView tgv, long long cell_first, long long cell_end,
                                                             int chunk, int2* __restrict__ units, int capacity,
                                                             int* __restrict__ count, int* __restrict__ count_next,
-                                                            int min_cnt, int* __restrict__ light) {
+                                                            int min_cnt, int* __restrict__ light, int pair_items = 0) {
   // count[0]: heavy units, count[1]: bodies of the most crowded cell, count[2]: the other units (the host reads the
   // sum and the maximum, one call late, to choose the kernel form and to size its grid), count[3]: bodies in `light`
   __shared__ int wsum[3][kBlock / 64], wmax[kBlock / 64];
@@ -2378,7 +2465,7 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
         if constexpr (BODIES) {
           lpos[k] = lo;
           lcnt[k] = cnt < min_cnt ? cnt : 0;
-          nu[2] += lcnt[k];
+          nu[2] += pair_items ? (lcnt[k] + 1) >> 1 : lcnt[k];  // (pair_items: one list entry per two bodies of a cell)
         }
         lo = hi;
         const int h = cnt > kHeavyCell ? 1 : 0;
@@ -2430,8 +2517,13 @@ __global__ __launch_bounds__(kBlock) void cell_units_kernel(const CellGridView t
   if constexpr (BODIES) {
     int lat = base_s[2] + before[2] + incl[2] - nu[2];
 #pragma unroll
-    for (int k = 0; k < kUnitCells; k++)
-      for (int q = 0; q < lcnt[k]; q++) light[lat++] = lpos[k] + q;
+    for (int k = 0; k < kUnitCells; k++) {
+      if (pair_items) {  // (sorted position of the first of two bodies; top bit: the cell's last, odd one)
+        for (int q = 0; q < lcnt[k]; q += 2) light[lat++] = (lpos[k] + q) | (q + 1 >= lcnt[k] ? (int)0x80000000u : 0);
+      } else {
+        for (int q = 0; q < lcnt[k]; q++) light[lat++] = lpos[k] + q;
+      }
+    }
   }
 }
 // the list's statistics for the host when the force kernel that follows is not the unit form (which exports them itself)
@@ -2451,7 +2543,8 @@ __global__ void cell_units_export_kernel(const int* __restrict__ count, int* __r
 
 // the work list of the cells [cell_first, cell_end) of grid gt (see cell_units_kernel); *cur: its two counters
 static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGridView& tv, long long cell_first,
-                          long long cell_end, int chunk, int** cur_out, int min_cnt = 1, bool bodies = false) {
+                          long long cell_end, int chunk, int** cur_out, int min_cnt = 1, bool bodies = false,
+                          bool pair_items = false) {
   const size_t nb = gt->built_count;
   const size_t need = nb + nb / 64 + 1024;  // an occupied cell is at least one unit; chunks hold >= 64 bodies
   if (need > gt->units_cap) {
@@ -2471,7 +2564,7 @@ static int make_unit_list(nbody_hip_ctx* ctx, nbody_hip_grid* gt, const CellGrid
   if (bodies) {
     if (!gt->d_light) NBH_HIP(hipMalloc(reinterpret_cast<void**>(&gt->d_light), gt->max_particles * sizeof(int)));
     hipLaunchKernelGGL(cell_units_kernel<true>, ugrid, dim3(kBlock), 0, ctx->stream, tv, cell_first, cell_end, chunk, gt->d_units,
-                       (int)gt->units_cap, cur, next, min_cnt, gt->d_light);
+                       (int)gt->units_cap, cur, next, min_cnt, gt->d_light, pair_items ? 1 : 0);
   } else {
     hipLaunchKernelGGL(cell_units_kernel<false>, ugrid, dim3(kBlock), 0, ctx->stream, tv, cell_first, cell_end, chunk, gt->d_units,
                        (int)gt->units_cap, cur, next, min_cnt, nullptr);
@@ -2486,6 +2579,17 @@ static int launch_cell_forces(nbody_hip_ctx* ctx, const CellGridView& tv, const 
                               float eps2, float G, float* ax, float* ay, float* az, float4* acc4, int accumulate,
                               nbody_hip_grid* gt = nullptr, int hint_slot = 0, int* prebuilt = nullptr) {
   if (cell_end <= cell_first) return NBODY_HIP_OK;
+  if (kern == 10 && (guard || cell_end - cell_first >= 0x7fffffffLL)) kern = 8;  // (eps ~ 0: the compare + select forms)
+  if (kern == 10) {  // two bodies of one cell per lane, every cell (see hash_body2_force_kernel)
+    if (!gt) return NBH_FAIL(NBODY_HIP_ERR_STATE, "the two-bodies-per-lane kernel needs the target grid");
+    int* cur = nullptr;
+    if (int rc = make_unit_list(ctx, gt, tv, cell_first, cell_end, 128, &cur, 0x7fffffff, true, true)) return rc;
+    const unsigned blocks = (unsigned)((gt->built_count + kBlock - 1) / kBlock);  // (at most one item per body)
+    hipLaunchKernelGGL(hash_body2_force_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, tv, sv, gt->d_keys_b, gx, gy, gz,
+                       cutoff2, eps2, G, ax, ay, az, acc4, accumulate, gt->d_light, cur + 3);
+    NBH_LAUNCH_CHECK();
+    return NBODY_HIP_OK;
+  }
   if (kern == 8 || kern == 9) {
     // 8: one lane per body for every body.  9 (the automatic form below kBodyBelow bodies per cell), SPLIT by cell: bodies
     // of cells with fewer than kSplitCnt bodies take one lane each; the cells of kSplitCnt and more -- the clumps of a
@@ -2674,7 +2778,8 @@ static int grid_forces_common(nbody_hip_grid* g, float cutoff, float G, float ep
       kern = n >= kSplitFrom ? 9 : 8;
     }
   }
-  if ((kern == 8 || kern == 9) && !g->lb_valid) kern = 1;  // (no start arrays: the cell-run kernel)
+  if ((kern == 8 || kern == 9 || kern == 10) && !g->lb_valid) kern = 1;  // (no start arrays: the cell-run kernel)
+  if (kern == 10 && guard) kern = 8;                                     // (eps ~ 0: the compare + select forms)
   if (kern != 1 && g->lb_valid) {
     const CellGridView view{g->d_sorted, g->d_cell_lb, g->d_idx_b, g->lb_base, g->lb_count};
     return launch_cell_forces(ctx, view, view, gx, gy, gz, g->lb_base, g->lb_base + g->lb_count, kern, guard, cutoff2,

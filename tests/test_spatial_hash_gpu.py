@@ -10,8 +10,8 @@ from gpu_util import HASH_C, hash_bound, hash_margin, acc_of, rel_err, to_device
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-KERNELS = (1, 2, 3, 4, 7, 8, 9)   # force kernels of the grid (nbody_hip_grid_tuning): cell runs; one wave per cell with 1 / 2 / 4 bodies per lane;
-                            # 7 = the two-phase form (distance masks, then the accepted candidates only); 8 = one lane per body; 9 = that for the light cells, a wave per crowded cell (the automatic form below 8 bodies per cell)
+KERNELS = (1, 2, 3, 4, 7, 8, 9, 10)   # force kernels of the grid (nbody_hip_grid_tuning): cell runs; one wave per cell with 1 / 2 / 4 bodies per lane;
+                            # 7 = the two-phase form (distance masks, then the accepted candidates only); 8 = one lane per body; 9 = that for the light cells, a wave per crowded cell (the automatic form below 8 bodies per cell); 10 = two bodies of a cell per lane
 
 
 # tests/test_spatial_hash.cpp:15-36 GridConstruction + :53-83 ComputeForces

@@ -39,7 +39,7 @@ def main():
         rho = n / grid.getTotalCells()
         ref = None
         line = f"N={n} cell={cell} cutoff={cutoff} rho={rho:.2f} build {tb:.3f} ms |"
-        for kern in (1, 2, 3, 4, 6, 7, 8, 9):
+        for kern in (1, 2, 3, 4, 6, 7, 8, 9, 10):
             grid.tuning(kern)
             t = timeit(lambda: grid.computeForces(d, cutoff, 1.0, 0.01))
             a = acc_of(d).astype(np.float64)
