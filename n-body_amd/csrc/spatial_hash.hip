@@ -2052,6 +2052,7 @@ struct nbody_hip_grid {
                                        // A/B), 2 = always (tests), default 1 = by the statistics of the previous call
   long long lb_capacity = 0;
   unsigned gap_tick = 0;          // which of the two gap-list counters this build uses (cell_mark_kernel)
+  bool gap_counters_clean = false;  // the two counters behind the start array are zero or in the alternating protocol
   bool lb_by_position = true;     // NBH_HASH_LB=cell: the per-cell search (cell_lb_kernel) instead
   bool lb_valid = false;
   long long lb_base = 0, lb_count = 0;  // cells [lb_base, lb_base + lb_count] covered by d_cell_lb
@@ -2324,10 +2325,12 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       NBH_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cell_lb), ((size_t)cap + extra) * sizeof(int)));
       g->lb_capacity = cap;
       NBH_HIP(hipMemsetAsync(g->d_cell_lb + cap, 0, 2 * sizeof(int), st));  // both counters of the gap list
+      g->gap_counters_clean = true;
       g->gap_tick = 0;
     }
     if (dense && count > 2LL * (long long)n) {  // more cells than bodies: two-level search (see cell_lb_coarse_kernel)
       int* coarse = g->d_cell_lb + g->lb_capacity;
+      g->gap_counters_clean = false;
       const long long ncoarse = count / kLbCoarse + 2;
       hipLaunchKernelGGL(cell_lb_coarse_kernel, dim3((unsigned)((ncoarse + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                          g->d_keys_b, ni, (int)base, (int)count, coarse);
@@ -2335,6 +2338,10 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
                          g->d_keys_b, (int)base, (int)count, coarse, g->d_cell_lb);
     } else if (dense && g->lb_by_position) {
       int* counters = g->d_cell_lb + g->lb_capacity;  // [2], then the list
+      if (!g->gap_counters_clean) {  // (the two-level search above keeps its coarse level in the same scratch area)
+        NBH_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int), st));
+        g->gap_counters_clean = true;
+      }
       int* cur = counters + (g->gap_tick & 1), *next = counters + ((g->gap_tick + 1) & 1);
       g->gap_tick++;
       hipLaunchKernelGGL(cell_mark_kernel, dim3((unsigned)((ni + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,

@@ -560,20 +560,23 @@ def test_key_pass_ahead_of_the_grid_record(nb, ctx, monkeypatch):
     n = 300000
     small = nb.ic.uniform_box(n, seed=31, lo=-9.0, hi=9.0)        # 19^3 cells: 13 key bits
     large = {k: (v * 3.5 if k.startswith("pos") else v) for k, v in small.items()}  # 64^3: 18 key bits
+    huge = {k: (v * 6.0 if k.startswith("pos") else v) for k, v in small.items()}   # 110^3 > 2 n cells: the two-level search
+                                                                                     # for the start array, whose coarse level
+                                                                                     # shares its scratch area with the gap list
     got = {}
     for mode, lb in (("0", "cell"), ("1", "position"), ("2", "position")):
         monkeypatch.setenv("NBH_HASH_SPECULATE", mode)
         monkeypatch.setenv("NBH_HASH_LB", lb)
         grid = nb.SpatialHashGrid(n, 1.0)
         res = []
-        for ic in (small, small, large, large, small):   # right, wrong (grown), right, wrong (shrunk)
+        for ic in (small, small, large, large, huge, large, huge, small):   # right, wrong (grown), right, ..., wrong (shrunk)
             d, _ = to_device(nb, ic)
             grid.build(d)
             grid.computeForces(d, 1.0, 1.0, 0.05)
             cs, ce, pc, si = grid.copyCellDataToHost()
             res.append((cs.copy(), ce.copy(), si.copy(), acc_of(d).copy(), grid.getTotalCells()))
         got[mode] = res
-    assert got["0"][0][4] < 2 ** 13 < 2 ** 17 < got["0"][2][4]
+    assert got["0"][0][4] < 2 ** 13 < 2 ** 17 < got["0"][2][4] < 2 * n < got["0"][4][4]
     for mode in ("1", "2"):
         for a, b in zip(got[mode], got["0"]):
             assert a[4] == b[4]
