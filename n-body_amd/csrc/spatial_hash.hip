@@ -826,7 +826,11 @@ __device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3]) {
 // KC consecutive cells per wave, software-pipelined: while the wave evaluates cell c out of LDS, the
 // loads of cell c+1's window are already in flight (into registers), so that only the first of a
 // wave's cells pays the global-memory latency of its lookups.
-constexpr int kCellsPerWave = 4;
+#ifndef NBH_HASH_KC
+#define NBH_HASH_KC 4
+#endif
+constexpr int kCellsPerWave = NBH_HASH_KC;  // (2 and 3 measured in round 4: 0.635 / 0.639-0.653 against 0.634-0.636 ms: no difference)
+static_assert(kCellsPerWave >= 1 && kCellsPerWave <= 4, "the lookups of a wave's cells are one round of 16 lanes per cell");
 constexpr double kFilterFrom = 40.0;  // bodies per cell from which the filtered form pays when cutoff > cell (see FILTER below)
 constexpr double kBodyBelow = 8.0;    // bodies per cell below which one lane takes one body (hash_body_force_kernel): 0.72 against
                                       // 0.96 ms at 6.6 per cell, 0.85 against 0.81 at 8.8 (profiles/r04_hash_kernels.txt)
