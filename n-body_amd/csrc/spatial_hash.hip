@@ -2211,14 +2211,22 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
   auto places_for = [&](SortImpl impl, int bits) {
     return impl != kSortPublic && bits <= kHistPlaces * NBH_HASH_RADIX_BITS ? (bits + NBH_HASH_RADIX_BITS - 1) / NBH_HASH_RADIX_BITS : 0;
   };
-  // the key pass (assign_cells_kernel) for a grid of `bits` key bits
-  auto key_pass = [&](int bits) {
+  // the key pass (assign_cells_kernel) and the sort for a grid of `bits` key bits:
+  // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
+  auto key_pass = [&](int bits) -> hipError_t {
     const SortImpl impl = pick_impl();
-    const size_t zero_words = impl == kSortDriver ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)bits) : 0;
+    const bool driver = impl == kSortDriver;
+    const size_t zero_words = driver ? onesweep::clear_words<NBH_HASH_RADIX_BITS>(n, 0u, (unsigned)bits) : 0;
+    const int hist_places = places_for(impl, bits);
     hipLaunchKernelGGL(assign_cells_kernel, dim3(std::min((ni + kHistThreads - 1) / kHistThreads, NBH_HIST_BLOCKS)), dim3(kHistThreads), 0, st, posm, ni, g->d_info,
                        g->cell_size, g->d_keys_a, static_cast<unsigned int*>(g->d_sort_tmp), (unsigned int)zero_words,
-                       g->d_hist, places_for(impl, bits));
+                       g->d_hist, hist_places);
+    size_t tmp = g->sort_tmp_bytes;
+    return sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n, bits, st,
+                               impl, /*cleared=*/driver, hist_places ? g->d_hist : nullptr, g->h_sort_err_dev);
   };
+  if (g->h_sort_err && *g->h_sort_err)
+    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "the radix sort of an earlier build gave up in its look-back (csrc/radix_sort.h)");
   int spec_bits = 0;  // the bit count the key pass has already been launched on (0: not yet)
   if (bounds) {
     GridInfo gi{};
@@ -2249,15 +2257,15 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
                        g->h_info_dev, g->d_hist, ++g->info_seq);
     NBH_LAUNCH_CHECK();
     g->enc_armed = true;
-    // The key pass does not wait for the host: what it needs of the grid it reads from the device's record, and the two
+    // The key pass and the sort do not wait for the host: what they need of the grid they read from the device's record, and the
     // launch parameters that depend on the grid (how many digit places to count, how many look-back words to clear)
     // depend on it only through the number of key bits -- which changes when the cell count crosses a power of two.  So
-    // it is launched on the PREVIOUS build's bit count before the record is polled, and runs while the host waits and
-    // prepares the sort; if the count turns out different (or the grid too large), the digit counts are zeroed and the
-    // pass repeated with the right one.  Removes the 9-11 us the GPU idled between grid_info_kernel and the key pass.
+    // they are launched on the PREVIOUS build's bit count before the record is polled, and run while the host waits; if
+    // the count turns out different (or the grid too large), the digit counts are zeroed and both repeated with the
+    // right one.  Removes the 9-11 us the GPU idled between grid_info_kernel and the key pass.
     if (g->spec_mode && g->last_sort_bits > 0) {
       spec_bits = g->spec_mode == 2 ? (g->last_sort_bits > 10 ? g->last_sort_bits - 10 : g->last_sort_bits + 10) : g->last_sort_bits;
-      key_pass(spec_bits);
+      NBH_HIP(key_pass(spec_bits));
     }
     // the one host round trip of the build: the grid size decides validity (and, for the
     // inspection API, allocation).  ref: 6 scalar cudaMemcpy D2H, force_spatial_hash.cu:213-218
@@ -2284,23 +2292,14 @@ static int grid_build_packed(nbody_hip_grid* g, float4* posm, size_t n, const fl
       return NBH_FAIL(NBODY_HIP_ERR_RESOURCE, "Spatial hash grid too large: reduce cell_size or bounding box");
   }
   const int sort_bits = bits_for(g->info.total);
-  if (g->h_sort_err && *g->h_sort_err)
-    return NBH_FAIL(NBODY_HIP_ERR_DEVICE, "the radix sort of an earlier build gave up in its look-back (csrc/radix_sort.h)");
   if (spec_bits != sort_bits) {
     if (spec_bits) {
       hipLaunchKernelGGL(hist_zero_kernel, dim3(1), dim3(256), 0, st, g->d_hist);
       NBH_LAUNCH_CHECK();
     }
-    key_pass(sort_bits);
+    NBH_HIP(key_pass(sort_bits));
   }
   g->last_sort_bits = sort_bits;
-  const SortImpl impl = pick_impl();
-  const bool driver = impl == kSortDriver;
-  const int hist_places = places_for(impl, sort_bits);
-  size_t tmp = g->sort_tmp_bytes;
-  // (keys, bodies, indices) -> cell order: d_keys_b, d_sorted, d_idx_b
-  NBH_HIP(sort_bodies_by_cell(g->d_sort_tmp, tmp, g->d_keys_a, g->d_keys_b, posm, g->d_sorted, g->d_idx_b, n,
-                              sort_bits, st, impl, /*cleared=*/driver, hist_places ? g->d_hist : nullptr, g->h_sort_err_dev));
   g->lb_valid = false;
   {
     // cells the per-cell start array covers: the whole grid, or the z layers of this rank's slab
